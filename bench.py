@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: particles/s splatted to a 1024^2 float32 buffer (+ ms/frame).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one frame of the hot path over the resident synthetic snapshot: splat kernels ->
+(N > 1) RCCL sum-reduce of the image to rank 0 -> colormap kernel on rank 0; synchronous, inputs
+already resident in HBM, upload/generation excluded.
+
+Workload (BASELINE.json configs[2]/[3]): dm density, 1024^2, camera A (identity rotation,
+scale 200), synthetic snapshot with the reference TestDataLoader distribution and h-law generated
+on device; weak scaling with 1.25e8 particles per GPU (N = 8 is the 1e9-particle config 4, N = 1
+is one such shard-sized snapshot, the single-GPU HBM-roofline config).  Particles are sharded by
+index range; the only collective is the image reduce.
+
+Prints ONE JSON line on rank 0 with the contract's keys plus `roofline` (dominant kernel, timed
+with hipEvents on the stream it runs on) and `cpu_baseline` (the CPU oracle, kind "port", on a
+bounded uniform sample of the same snapshot on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+B_ALG = {"density": 20, "weighted": 24, "rgb": 28}     # algorithmic bytes/particle
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--particles-per-gpu", type=float, default=1.25e8)
+    ap.add_argument("--resolution", type=int, default=1024)
+    ap.add_argument("--scale", type=float, default=200.0)
+    ap.add_argument("--h-cap-px", type=float, default=0.0,
+                    help="cap smoothing lengths so footprints are <= this many pixels (bandwidth-bound variant)")
+    ap.add_argument("--mode", choices=["density", "weighted", "rgb"], default="density")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--generic", action="store_true", help="use the generic (global-atomic) kernel")
+    ap.add_argument("--no-reorder", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from topsy_amd import _native, kernel_lut
+
+    R = args.resolution
+    n_per = int(args.particles_per_gpu)
+    n_total = n_per * world
+    mode = {"density": _native.MODE_WEIGHTED, "weighted": _native.MODE_WEIGHTED, "rgb": _native.MODE_RGB}[args.mode]
+    ctx = _native.Context(R, 4 if args.mode == "rgb" else 2, device_id=local_rank)
+    ctx.set_kernel_mips(kernel_lut.kernel_mips())
+    h_cap = args.h_cap_px * args.scale / (2.0 * R) if args.h_cap_px > 0 else 0.0
+    t_setup = time.time()
+    ctx.generate_synthetic(n_total, first=rank * n_per, count=n_per, seed=1337, h_cap=h_cap,
+                           with_quantity=args.mode == "weighted", with_rgb=args.mode == "rgb")
+    if not args.no_reorder:
+        ctx.reorder_spatial(32, 1337)       # load-time ordering (config.SPATIAL_ORDER_STRATA)
+    t_setup = time.time() - t_setup
+
+    if world > 1:
+        ids = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(world, rank, ids[0])
+
+    # camera A (reference default view): identity rotation, zero offset
+    M = np.eye(4, dtype=np.float32)
+    M[:3, :3] /= args.scale
+    M[2, :] = [0.0, 0.0, 0.5 / args.scale, 0.5]
+    sf = np.float32(1.0 / args.scale)
+    import matplotlib
+    lut = matplotlib.colormaps["twilight_shifted"](np.linspace(0.001, 0.999, 1000)).astype(np.float32)
+    flags = _native.PIPE_GENERIC if args.generic else _native.PIPE_DEFAULT
+
+    kernel_ms = {"stream": [], "mid": [], "huge": [], "total": [], "reduce": []}
+    vmin, vmax = -12.0, -4.0
+
+    def frame(record):
+        ctx.render(M, sf, clear=True, mode=mode, flags=flags)
+        if record:
+            st = ctx.stats()
+            kernel_ms["stream"].append(st["ms_stream"]); kernel_ms["mid"].append(st["ms_mid"])
+            kernel_ms["huge"].append(st["ms_huge"]); kernel_ms["total"].append(st["ms_total"])
+        if world > 1:
+            ms = ctx.comm_reduce_image(root=0)
+            if record:
+                kernel_ms["reduce"].append(ms)
+        if rank == 0:
+            if args.mode == "rgb":
+                return ctx.colormap_rgb(vmin, vmax, 1.0)
+            return ctx.colormap_scalar(lut, vmin, vmax, True, args.mode == "weighted")
+        return None
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        frame(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = frame(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ctx.set_option("count_fragments", 1)
+    ctx.render(M, sf, clear=True, mode=mode, flags=_native.PIPE_GENERIC if args.generic else flags)
+    st = ctx.stats()
+    ctx.set_option("count_fragments", 0)
+    frags = st["n_fragments"]
+    if dist is not None:
+        f = torch.tensor([float(frags)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(f)
+        frags = f.item()
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_total / (elapsed / args.steps)
+    # dominant kernel of the frame and its roofline (HBM: B_alg bytes/particle streamed once)
+    means = {k: float(np.mean(v)) if v else 0.0 for k, v in kernel_ms.items()}
+    parts = {k: means[k] for k in ("stream", "mid", "huge")}
+    if sum(parts.values()) <= 0.0:
+        dom, dom_ms = "splat_generic_kernel", means["total"]
+    else:
+        dom = max(parts, key=parts.get)
+        dom_ms = parts[dom]
+        dom = {"stream": "splat_stream_kernel", "mid": "splat_mid_kernel", "huge": "splat_huge_kernel"}[dom]
+    bytes_per_launch = B_ALG[args.mode] * n_per
+    achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    stream_ms = means["stream"] if means["stream"] > 0 else means["total"]
+    measured_peak = ctx.measure_read_bandwidth(1 << 30, 10)
+    result = {
+        "metric": "particles/sec splatted to 1024^2 buffer",
+        "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{n_total:.4g} dm particles ({n_per:.4g}/GPU), {args.mode}, {R}^2 buffer, camera A "
+                               f"(scale {args.scale:g}), reference TestDataLoader h-law"
+                               + (f", h capped at {args.h_cap_px:g} px" if args.h_cap_px > 0 else "")
+                               + ", splat + " + ("RCCL image reduce + " if world > 1 else "") + "colormap",
+                   "particles_per_gpu": n_per, "resolution": R, "sharding": f"index-range x{world}",
+                   "pipeline": "generic" if args.generic else "three-class",
+                   "fragments_per_particle": frags / n_total, "frames_per_s": 1e3 / ms_per_step},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": dom_ms,
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "measured_read_peak_GBps": measured_peak,
+                     "stream_kernel_ms": stream_ms,
+                     "stream_kernel_GBps": bytes_per_launch / (stream_ms * 1e-3) / 1e9 if stream_ms > 0 else 0.0},
+        "kernel_ms": means,
+        "setup_s": t_setup,
+    }
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args, n_total, M, sf, R)
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, n_total, M, sf, R):
+    """The CPU oracle (C restatement, OpenMP over all host cores) on a bounded uniform sample of the
+    same snapshot: rows [0, n_s) of the generator's index bijection are a uniform sample."""
+    from topsy_amd import _native, kernel_lut
+    from oracle import oracle_c
+    mips = kernel_lut.kernel_mips()
+    cores = oracle_c.max_threads()
+    h_cap = args.h_cap_px * args.scale / (2.0 * R) if args.h_cap_px > 0 else 0.0
+
+    def sample(n_s):
+        c = _native.Context(64, 2, device_id=int(os.environ.get("LOCAL_RANK", "0")))
+        c.generate_synthetic(n_total, first=0, count=n_s, seed=1337, h_cap=h_cap)
+        d = c.download_particles(("x", "y", "z", "h", "mass"))
+        c.close()
+        return d
+
+    def run(d):
+        t = time.perf_counter()
+        oracle_c.splat(d["x"], d["y"], d["z"], d["h"], d["mass"], None, None, mode=0, M=M, sf=float(sf), R=R, mips=mips)
+        return time.perf_counter() - t
+
+    pilot_n = 20000
+    d = sample(pilot_n)
+    run(d)
+    pilot = run(d)
+    n_s = int(min(max(pilot_n * args.cpu_seconds / max(pilot, 1e-4), pilot_n), 5e7, n_total))
+    d = sample(n_s)
+    secs = run(d)
+    return {"value": n_s / secs, "unit": "particles/s", "cores": cores, "kind": "port",
+            "sample": f"{n_s} particles (uniform sample of the {n_total:.4g}-particle snapshot, same camera, {R}^2, "
+                      f"density), oracle/oracle.c OpenMP, {secs:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+/* topsy_splat.h -- C-ABI of the MI355X-native SPH particle-splatting backend for topsy.
+ *
+ * This is the drop-in boundary for ONE hot path of pynbody/topsy: per-particle smoothing-kernel
+ * rasterisation into a float32 image (reference src/topsy/sph.py + shaders/sph.wgsl) and the
+ * 1-D-LUT / log-scale colormap post-pass (reference src/topsy/colormap/implementation.py +
+ * shaders/colormap.wgsl).  In the reference that path sits behind a Python object protocol
+ * (Visualizer <-> SPH / ColormapHolder) whose device side is wgpu; here the device side is this
+ * library (hand-written HIP for gfx950) and the Python side (topsy_amd/) binds it with ctypes.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success, a negative TSP_E* code on error;
+ *     tsp_last_error() gives the text of the most recent failure on the calling thread.
+ *   - the caller owns every host array; the library copies on upload and writes only into
+ *     caller-allocated output buffers.  No callbacks, no exceptions cross the boundary.
+ *   - one context = one GPU (one process per GPU for multi-GPU; see tsp_comm_*).  Calls on one
+ *     context must be serialised by the caller.  All calls are synchronous (they return after
+ *     the GPU work they issued has completed), mirroring the reference's
+ *     submit + on_submitted_work_done_sync pairs (src/topsy/util.py:84-99).
+ *   - images are row-major, row 0 = top (+y), channels interleaved: float32 [R][R][C].
+ */
+#ifndef TOPSY_SPLAT_H
+#define TOPSY_SPLAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tsp_context tsp_context;
+
+enum {
+    TSP_OK = 0,
+    TSP_EINVAL = -1,   /* bad argument */
+    TSP_EHIP = -2,     /* HIP runtime error (text in tsp_last_error) */
+    TSP_ENODEV = -3,   /* no usable GPU */
+    TSP_ESTATE = -4,   /* call order violated (e.g. render before upload / before kernel LUT) */
+    TSP_ECOMM = -5,    /* RCCL error */
+    TSP_ENOMEM = -6
+};
+
+/* Render modes: which per-particle channels feed the image (reference SPH subclasses). */
+enum {
+    TSP_MODE_WEIGHTED = 0, /* SPH: ch0 += k*m/h^2, ch1 += k*m/h^2*q      (sph.wgsl:76-83,139-146)  C=2 */
+    TSP_MODE_DEPTH = 1,    /* DepthSPH: ch1 weights by clip-space z       (sph.wgsl:86-91)          C=2 */
+    TSP_MODE_RGB = 2       /* RGBSPH: ch0..2 += k*(r,g,b)/h^2, ch3 += 1   (sph.wgsl:69-73,161-165)  C=4 */
+};
+
+/* Pipeline selection for tsp_render (flags argument). 0 = default (fast three-class pipeline). */
+enum {
+    TSP_PIPE_DEFAULT = 0,
+    TSP_PIPE_GENERIC = 1   /* single generic kernel, global atomics only (cross-check / debugging) */
+};
+
+const char *tsp_last_error(void);
+int tsp_version(void);
+
+/* Number of visible GPUs (hipGetDeviceCount); <0 on error. Does not create a HIP context. */
+int tsp_device_count(void);
+
+/* Create a renderer for one GPU.  Mirrors SPH.__init__ (reference src/topsy/sph.py:50-88):
+ * allocates the R x R x C float32 render target.  n_channels: 2 (SPH / DepthSPH, rg32float,
+ * sph.py:23) or 4 (RGBSPH, rgba32float, sph.py:432-439). */
+int tsp_create(int device_id, int resolution, int n_channels, tsp_context **out);
+void tsp_destroy(tsp_context *ctx);
+
+/* Kernel texture: n_levels mip levels of sizes n0, n0/2, ... concatenated, float32
+ * (reference SPH._setup_kernel_texture, src/topsy/sph.py:396-426; n0 = 64, n_levels = 4).
+ * Sampler semantics are fixed to the reference's: mag linear, min/mip nearest, clamp-to-edge. */
+int tsp_set_kernel_mips(tsp_context *ctx, const float *lut, int n0, int n_levels);
+
+/* Particle upload, SoA float32, caller's (global) index order is preserved.
+ * Replaces ParticleBuffers.get_pos_smooth_buffers / get_mass_and_quantity_buffers /
+ * get_rgb_buffers (reference src/topsy/particle_buffers.py:84-118).
+ * mass may be NULL for a context that will only render TSP_MODE_RGB. */
+int tsp_upload_particles(tsp_context *ctx, int64_t n, const float *x, const float *y, const float *z,
+                         const float *h, const float *mass);
+/* q == NULL selects the density render (reference uploads q = 0 then, particle_buffers.py:96-99;
+ * quantity swap: src/topsy/visualizer.py:294-309). */
+int tsp_upload_quantity(tsp_context *ctx, const float *q);
+int tsp_upload_rgb(tsp_context *ctx, const float *r, const float *g, const float *b);
+
+/* On-device synthetic snapshot = restatement of topsy.loader.TestDataLoader's distribution
+ * (reference src/topsy/loader.py:241-332) with a counter-based generator, so that shard
+ * [first, first+count) of an n_total-particle snapshot is reproducible on any GPU without
+ * materialising n_total rows on the host.  h_cap > 0 caps the smoothing length (bandwidth-bound
+ * variant of BASELINE.md section 3); with_quantity / with_rgb also fill q / rgb. */
+int tsp_generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int64_t count,
+                           uint64_t seed, float h_cap, int with_quantity, int with_rgb);
+
+/* Load-time spatial ordering (the analogue of the reference's CellLayout sort at load,
+ * src/topsy/loader.py:88-97): reorders the resident particles into n_strata uniform random
+ * strata, each Morton-sorted, so that index prefixes remain unbiased samples (progressive
+ * rendering) while consecutive indices are screen-coherent.  perm_out (optional, host, n
+ * int64) receives new->old indices.  Later tsp_upload_quantity/rgb calls are given in the OLD
+ * order and permuted by the library. */
+int tsp_reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out);
+
+/* Copy resident particle arrays back (testing / fixtures). Any pointer may be NULL. */
+int tsp_download_particles(tsp_context *ctx, float *x, float *y, float *z, float *h, float *mass,
+                           float *q, float *r, float *g, float *b);
+int64_t tsp_num_particles(tsp_context *ctx);
+
+/* One render block.  Replaces the body of SPH.render's loop (reference src/topsy/sph.py:318-326:
+ * encode_render_pass(clear) + update_particle_ranges(starts, lens) + timed queue.submit).
+ *   M             row-major 4x4, clip = M * (x,y,z,1)  (= transpose of the reference's uploaded
+ *                 "transform", src/topsy/sph.py:268-289)
+ *   scale_factor  1/scale (sph.wgsl:58)
+ *   starts/lens   n_ranges particle index ranges (first_instance, instance_count of the
+ *                 reference's indirect draws, particle_buffers.py:76-82); NULL = all particles
+ *   clear         1 = clear the target first (load_op clear, sph.py:346)
+ *   mode          TSP_MODE_*
+ *   flags         TSP_PIPE_*
+ *   gpu_ms_out    optional: GPU time of this block (hipEvent pair) -- the TimeGpuOperation hook */
+int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64_t *starts,
+               const int64_t *lens, int n_ranges, int clear, int mode, int flags, double *gpu_ms_out);
+
+/* Read the render target (R*R*C float32).  SPH._get_image_unscaled, src/topsy/sph.py:127-140. */
+int tsp_read_image(tsp_context *ctx, float *out);
+/* Overwrite the render target from the host (testing the colormap on a known buffer). */
+int tsp_write_image(tsp_context *ctx, const float *in);
+
+/* Colormap post-pass on the resident render target -> RGBA8 (R*R*4 bytes, RGBA order).
+ * scalar: colormap.wgsl fragment_main non-bivariate branch (:113-127); lut = n_lut x RGBA float32
+ * (Colormap._generate_mapping_rgba_f32, implementation.py:235-238); vmin/vmax are the
+ * already-scaled shader parameters (Colormap._update_parameter_buffer, implementation.py:427-453). */
+int tsp_colormap_scalar(tsp_context *ctx, const float *lut_rgba, int n_lut, float vmin, float vmax,
+                        int log_scale, int weighted, uint8_t *out_rgba);
+/* rgb: colormap.wgsl fragment_main_tri + gamma_map (:131-159).  out_rgba8 and/or out_rgba_f32
+ * (unclamped, the HDR canvas value) may be NULL. */
+int tsp_colormap_rgb(tsp_context *ctx, float vmin, float vmax, float gamma, uint8_t *out_rgba8,
+                     float *out_rgba_f32);
+
+/* Same maps applied to an arbitrary host image (H x W x C float32), the entry
+ * Colormap.sph_raw_output_to_image drives (implementation.py:132-201). */
+int tsp_colormap_scalar_host(tsp_context *ctx, const float *img, int H, int W, int C,
+                             const float *lut_rgba, int n_lut, float vmin, float vmax, int log_scale,
+                             int weighted, uint8_t *out_rgba);
+int tsp_colormap_rgb_host(tsp_context *ctx, const float *img, int H, int W, int C, float vmin,
+                          float vmax, float gamma, uint8_t *out_rgba8, float *out_rgba_f32);
+
+/* Counters of the last tsp_render call (measurement aid). */
+typedef struct {
+    int64_t n_particles;   /* particles visited (sum of range lengths) */
+    int64_t n_small;       /* splatted by the streaming kernel */
+    int64_t n_mid;         /* nearest-mip footprints deferred to the tile-scatter kernel */
+    int64_t n_huge;        /* bilinear footprints (P >= 64 px) deferred to the tile-gather kernel */
+    int64_t n_culled;      /* z-slab / off-screen / non-finite */
+    int64_t n_fragments;   /* pixel updates (only counted when TSP_STATS is enabled) */
+    double ms_stream, ms_mid, ms_huge, ms_total; /* per-kernel GPU time, hipEvents */
+} tsp_stats;
+int tsp_get_stats(tsp_context *ctx, tsp_stats *out);
+/* Enable fragment counting (adds atomics; off by default). */
+int tsp_set_option(tsp_context *ctx, const char *name, int64_t value);
+
+/* Streaming-read microbenchmark (float4 read-sum over `bytes` of device memory): returns GB/s.
+ * The measured HBM peak BASELINE.md section 2 prices the roofline fraction against. */
+int tsp_measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, double *gbps_out);
+
+/* Multi-GPU: one process per GPU, particles sharded by index range, partial images summed
+ * with ONE RCCL reduce over xGMI (the reference has no counterpart).
+ * Rank 0 calls tsp_comm_unique_id and distributes the 128-byte id out-of-band. */
+#define TSP_UNIQUE_ID_BYTES 128
+int tsp_comm_unique_id(char *id_out);
+int tsp_comm_init(tsp_context *ctx, int n_ranks, int rank, const char *id);
+/* Sum-reduce the render target to `root` (or to every rank when root < 0), float32, in place. */
+int tsp_comm_reduce_image(tsp_context *ctx, int root, double *gpu_ms_out);
+int tsp_comm_destroy(tsp_context *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOPSY_SPLAT_H */

@@ -1,0 +1,320 @@
+/* CPU ORACLE (C restatement) -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Restates topsy's SPH splat + colormap hot path on the CPU so the HIP kernels can be checked
+ * against it at sizes the numpy twin (oracle_np.py) cannot reach, and serves as the timed
+ * `cpu_baseline` ("port") in bench.py.  The product (topsy_amd/) never links, loads or calls it.
+ *
+ * Parity status: PINNED -- tests/test_oracle_golden.py checks it against every known-answer
+ * vector of the reference's own tests (tests/golden/reference_kats.npz) and bit-for-bit against
+ * oracle_np.py.
+ *
+ * Reference lines followed (relative to /root/reference):
+ *   vertex stage ............ src/topsy/shaders/sph.wgsl:54-83   (orc_project)
+ *   rasteriser + fragment ... src/topsy/shaders/sph.wgsl:139-146,161-165 ; blend src/topsy/sph.py:31-42
+ *   kernel texture sampler .. src/topsy/sph.py:396-426 (4 mips, mag linear / min+mip nearest)
+ *   colormap ................ src/topsy/shaders/colormap.wgsl:75-159
+ *   range blocks ............ src/topsy/particle_buffers.py:70-82 (first_instance, instance_count)
+ *
+ * The canonical float32 operation order is documented at the top of oracle_np.py; this file must
+ * be compiled with -ffp-contract=off and without -ffast-math.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define P_BILINEAR 64.0f
+#define P_L0 45.254833995939045f
+#define P_L1 22.627416997969522f
+#define P_L2 11.313708498984761f
+
+static const int MIP_N[4] = {64, 32, 16, 8};
+static const int MIP_OFF[4] = {0, 4096, 5120, 5376};
+
+typedef struct {
+    float pcx, pcy, cz, P, half, invP;
+    int keep;
+} proj_t;
+
+/* sph.wgsl:54-66 in pixel units */
+static inline proj_t orc_project(const float *M, float sf, float Rf, float x, float y, float z, float h) {
+    proj_t r;
+    float cx = ((M[0] * x + M[1] * y) + M[2] * z) + M[3];
+    float cy = ((M[4] * x + M[5] * y) + M[6] * z) + M[7];
+    r.cz = ((M[8] * x + M[9] * y) + M[10] * z) + M[11];
+    float s = (sf * h) * 2.0f;
+    float halfR = 0.5f * Rf;
+    r.P = s * Rf;
+    r.half = 0.5f * r.P;
+    r.pcx = (cx + 1.0f) * halfR;
+    r.pcy = (1.0f - cy) * halfR;
+    r.invP = 1.0f / r.P;
+    r.keep = (r.cz >= 0.0f) && (r.cz <= 1.0f) && isfinite(r.P) && (r.P > 0.0f) && isfinite(r.pcx) && isfinite(r.pcy);
+    return r;
+}
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* candidate pixel interval (conservative), the exact test is |d| < half */
+static inline void cand(float pc, float half, int R, int *lo, int *hi) {
+    float a = floorf(pc - half - 0.5f) - 1.0f;
+    float b = ceilf(pc + half - 0.5f) + 1.0f;
+    if (a < 0.0f) a = 0.0f;
+    if (b > (float)(R - 1)) b = (float)(R - 1);
+    *lo = (int)a;
+    *hi = (int)b;
+}
+
+static inline int level_for(float P) {
+    if (P >= P_BILINEAR) return -1;
+    if (P > P_L0) return 0;
+    if (P > P_L1) return 1;
+    if (P > P_L2) return 2;
+    return 3;
+}
+
+/* One axis of texture addressing, precomputed per covered pixel column/row. */
+typedef struct {
+    int i0, i1;
+    float f;
+} axis_t;
+
+static inline axis_t axis_bilinear(float u) {
+    axis_t a;
+    float tu = u * 64.0f - 0.5f;
+    float x0 = floorf(tu);
+    a.f = tu - x0;
+    a.i0 = clampi((int)x0, 0, 63);
+    a.i1 = clampi((int)x0 + 1, 0, 63);
+    return a;
+}
+
+static inline int axis_nearest(float u, int n) { return clampi((int)floorf(u * (float)n), 0, n - 1); }
+
+/* Splat one particle into acc (R*R*C doubles).  nch = 2 (w[0]=m/h^2, w[1]=q), 4 = rgb + count. */
+static void splat_one(double *acc, int R, int C, const float *mips, proj_t pr, const float *w, long *nfrag) {
+    int ilo, ihi, jlo, jhi;
+    cand(pr.pcx, pr.half, R, &ilo, &ihi);
+    cand(pr.pcy, pr.half, R, &jlo, &jhi);
+    if (ihi < ilo || jhi < jlo) return;
+    int lvl = level_for(pr.P);
+    for (int j = jlo; j <= jhi; ++j) {
+        float dy = ((float)j + 0.5f) - pr.pcy;
+        if (!(fabsf(dy) < pr.half)) continue;
+        float v = (dy + pr.half) * pr.invP;
+        axis_t ay = {0, 0, 0.f};
+        int ty = 0;
+        if (lvl < 0) ay = axis_bilinear(v); else ty = axis_nearest(v, MIP_N[lvl]);
+        for (int i = ilo; i <= ihi; ++i) {
+            float dx = ((float)i + 0.5f) - pr.pcx;
+            if (!(fabsf(dx) < pr.half)) continue;
+            float u = (dx + pr.half) * pr.invP;
+            float k;
+            if (lvl < 0) {
+                axis_t ax = axis_bilinear(u);
+                const float *T = mips;
+                float gx = 1.0f - ax.f, gy = 1.0f - ay.f;
+                float top = T[ay.i0 * 64 + ax.i0] * gx + T[ay.i0 * 64 + ax.i1] * ax.f;
+                float bot = T[ay.i1 * 64 + ax.i0] * gx + T[ay.i1 * 64 + ax.i1] * ax.f;
+                k = top * gy + bot * ay.f;
+            } else {
+                int n = MIP_N[lvl];
+                k = mips[MIP_OFF[lvl] + ty * n + axis_nearest(u, n)];
+            }
+            double *px = acc + ((size_t)j * R + i) * C;
+            if (C == 2) {
+                float val = k * w[0];
+                px[0] += val;
+                px[1] += (float)(val * w[1]);
+            } else {
+                px[0] += (float)(k * w[0]);
+                px[1] += (float)(k * w[1]);
+                px[2] += (float)(k * w[2]);
+                px[3] += 1.0;
+            }
+            if (nfrag) ++*nfrag;
+        }
+    }
+}
+
+/* mode: 0 = mass + quantity (vertex_weighting), 1 = depth (vertex_depth: w[1] = clip z), 2 = rgb.
+ * a,b,c: mode 0: a=mass, b=qty (may be NULL -> 0), c unused; mode 1: a=mass; mode 2: a,b,c = r,g,b.
+ * starts/lens: particle index ranges (NULL -> all).  out: R*R*C float32 (C = 2 or 4).
+ * accumulate != 0 adds to `out` instead of overwriting.  Returns total fragment count. */
+long orc_splat(long n, const float *x, const float *y, const float *z, const float *h,
+               const float *a, const float *b, const float *c, int mode,
+               const float *M, float sf, int R, const float *mips,
+               const int64_t *starts, const int64_t *lens, int nranges,
+               int accumulate, int nthreads, float *out) {
+    const int C = (mode == 2) ? 4 : 2;
+    const size_t npx = (size_t)R * R * C;
+    int64_t s0 = 0, l0 = n;
+    if (!starts) { starts = &s0; lens = &l0; nranges = 1; }
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+    double **accs = (double **)calloc(nthreads, sizeof(double *));
+    long total_frag = 0;
+    const float Rf = (float)R;
+#pragma omp parallel num_threads(nthreads) reduction(+ : total_frag)
+    {
+#ifdef _OPENMP
+        int tid = omp_get_thread_num();
+#else
+        int tid = 0;
+#endif
+        double *acc = (double *)calloc(npx, sizeof(double));
+        accs[tid] = acc;
+        long nf = 0;
+        for (int r = 0; r < nranges; ++r) {
+            int64_t beg = starts[r], end = starts[r] + lens[r];
+            if (beg < 0) beg = 0;
+            if (end > n) end = n;
+#pragma omp for schedule(static) nowait
+            for (int64_t p = beg; p < end; ++p) {
+                proj_t pr = orc_project(M, sf, Rf, x[p], y[p], z[p], h[p]);
+                if (!pr.keep) continue;
+                float w[3] = {0.f, 0.f, 0.f};
+                float hh = h[p] * h[p];
+                if (mode == 2) {
+                    w[0] = a[p] / hh; w[1] = b[p] / hh; w[2] = c[p] / hh;
+                } else {
+                    w[0] = a[p] / hh;
+                    w[1] = (mode == 1) ? pr.cz : (b ? b[p] : 0.0f);
+                }
+                splat_one(acc, R, C, mips, pr, w, &nf);
+            }
+        }
+        total_frag += nf;
+    }
+    /* deterministic reduction over threads, in thread order */
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (size_t i = 0; i < npx; ++i) {
+        double s = 0.0;
+        for (int t = 0; t < nthreads; ++t)
+            if (accs[t]) s += accs[t][i];
+        out[i] = accumulate ? (float)((double)out[i] + s) : (float)s;
+    }
+    for (int t = 0; t < nthreads; ++t) free(accs[t]);
+    free(accs);
+    return total_frag;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * canonical float32 log / exp (see oracle_np.py) and the colormap (colormap.wgsl:75-159)
+ * ------------------------------------------------------------------------------------------ */
+static inline float as_f(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
+static inline int32_t as_i(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
+
+float orc_logf(float x) {
+    if (x != x || x < 0.0f) return NAN;
+    if (x == 0.0f) return -INFINITY;
+    if (isinf(x)) return INFINITY;
+    int eadj = 0;
+    if (x < 1.17549435e-38f) { x = x * 8388608.0f; eadj = -23; }
+    int32_t bits = as_i(x);
+    int e = ((bits >> 23) & 0xff) - 127 + eadj;
+    float m = as_f((bits & 0x007fffff) | 0x3f800000);
+    if (m > 1.41421354f) { m = m * 0.5f; e += 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float z = s * s;
+    float p = 0.18181819f;
+    p = p * z + 0.22222222f;
+    p = p * z + 0.2857143f;
+    p = p * z + 0.4f;
+    p = p * z + 0.6666667f;
+    float lm = (s + s) + (s * z) * p;
+    float ef = (float)e;
+    return (ef * 0.693359375f + lm) + ef * -2.12194440e-4f;
+}
+
+float orc_expf(float y) {
+    if (y != y) return NAN;
+    if (y > 88.72f) return INFINITY;
+    if (y < -103.9f) return 0.0f;
+    float nf = floorf(y * 1.44269504f + 0.5f);
+    float r = (y - nf * 0.693359375f) - nf * -2.12194440e-4f;
+    float p = 1.9841270e-4f;
+    p = p * r + 1.3888889e-3f;
+    p = p * r + 8.3333333e-3f;
+    p = p * r + 4.1666667e-2f;
+    p = p * r + 0.16666667f;
+    p = p * r + 0.5f;
+    p = p * r + 1.0f;
+    p = p * r + 1.0f;
+    int n = (int)nf;
+    int n1 = clampi(n, -126, 127);
+    int n2 = clampi(n - n1, -126, 127);
+    return (p * as_f((n1 + 127) << 23)) * as_f((n2 + 127) << 23);
+}
+
+static inline float orc_log10f(float x) { return orc_logf(x) / 2.30258509f; }
+
+float orc_powf(float x, float g) {
+    if (g == 1.0f) return x;
+    if (x == 0.0f && g > 0.0f) return 0.0f;
+    if (g == 0.0f && x == x) return 1.0f;
+    return orc_expf(g * orc_logf(x));
+}
+
+static inline uint8_t unorm8(float c) {
+    if (c != c) c = 0.0f;
+    if (c < 0.0f) c = 0.0f;
+    if (c > 1.0f) c = 1.0f;
+    return (uint8_t)floorf(c * 255.0f + 0.5f);
+}
+
+/* fragment_main, non-bivariate (colormap.wgsl:113-127).  img: npix x C floats (C >= 2). */
+void orc_colormap_scalar(const float *img, long npix, int C, const float *lut, int nlut,
+                         float vmin, float vmax, int log_scale, int weighted, uint8_t *out) {
+    float range = vmax - vmin;
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < npix; ++p) {
+        float v = weighted ? img[p * C + 1] / img[p * C] : img[p * C];
+        if (log_scale) v = orc_log10f(v);
+        float t = (v - vmin) / range;
+        if (t != t) t = 0.0f;
+        if (t < 0.0f) t = 0.0f;
+        if (t > 1.0f) t = 1.0f;
+        float c = t * (float)nlut - 0.5f;
+        float c0 = floorf(c);
+        float f = c - c0;
+        int i0 = clampi((int)c0, 0, nlut - 1), i1 = clampi((int)c0 + 1, 0, nlut - 1);
+        float g = 1.0f - f;
+        for (int k = 0; k < 4; ++k) out[p * 4 + k] = unorm8(lut[i0 * 4 + k] * g + lut[i1 * 4 + k] * f);
+    }
+}
+
+/* fragment_main_tri + gamma_map (colormap.wgsl:131-159), LOG_SCALE on.  outf (optional) gets the
+ * unclamped float RGBA (HDR path), out8 (optional) the unorm8 store. */
+void orc_colormap_rgb(const float *img, long npix, int C, float vmin, float vmax, float gamma,
+                      uint8_t *out8, float *outf) {
+    float range = vmax - vmin;
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < npix; ++p) {
+        for (int k = 0; k < 3; ++k) {
+            float v = orc_log10f(img[p * C + k]);
+            float xx = (v - vmin) / range;
+            if (xx != xx) xx = 0.0f;
+            if (xx < 0.0f) xx = 0.0f;
+            float c = orc_powf(xx, gamma);
+            if (out8) out8[p * 4 + k] = unorm8(c);
+            if (outf) outf[p * 4 + k] = c;
+        }
+        if (out8) out8[p * 4 + 3] = 255;
+        if (outf) outf[p * 4 + 3] = 1.0f;
+    }
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

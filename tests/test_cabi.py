@@ -1,0 +1,54 @@
+"""The C-ABI library loads here (no GPU) and exports every symbol include/topsy_splat.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "topsy_splat.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    from topsy_amd import _native
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    assert sorted(_native.SIGNATURES) == declared
+
+
+def test_library_exports_every_declared_symbol():
+    from topsy_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(lib, name), f"{name} is declared in include/topsy_splat.h but not exported"
+    assert _native.load_library().tsp_version() >= 100
+
+
+def test_no_gpu_fails_loudly():
+    """Without a GPU the product must raise -- never fall back to a CPU path."""
+    from topsy_amd import _native
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_native.BackendUnavailable):
+        _native.Context(64, 2)
+    import topsy_amd
+    with pytest.raises(_native.BackendUnavailable):
+        topsy_amd.test(100, render_resolution=32)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "topsy_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "liboracle" not in src and "oracle/" not in src.replace("the CPU oracle under oracle/", ""), f

@@ -1,0 +1,274 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (BASELINE.md section 5 / north_star): density channel <= 1e-5 relative; weighted channel
+absolute tolerance scaled by the per-pixel sum of |terms| (it can cancel); colormap uint8 bit-exact
+on the identical float buffer.
+"""
+import numpy as np
+import pytest
+
+from conftest import make_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from topsy_amd import _native
+    _native.load_library()
+    return _native
+
+
+def oracle_render(pos, h, a, b, c, mode, M, sf, R, mips, ranges=None):
+    from oracle import oracle_c
+    x, y, z = (np.ascontiguousarray(pos[:, k]) for k in range(3))
+    return oracle_c.splat(x, y, z, h, a, b, c, mode=mode, M=M, sf=sf, R=R, mips=mips, ranges=ranges)
+
+
+def abs_terms_image(pos, h, m, q, M, sf, R, mips):
+    """sum of |val * q| per pixel: the scale of the weighted channel's rounding noise."""
+    img, _ = oracle_render(pos, h, m, np.abs(q), None, 0, M, sf, R, mips)
+    return img[..., 1]
+
+
+def check_2ch(got, want, abs_terms, rtol=1e-5):
+    d0 = np.abs(got[..., 0] - want[..., 0])
+    assert (d0 <= rtol * np.abs(want[..., 0]) + 1e-30).all(), \
+        f"density channel: max rel err {np.max(d0 / np.maximum(np.abs(want[..., 0]).astype(np.float64), 1e-300))}"
+    d1 = np.abs(got[..., 1] - want[..., 1])
+    assert (d1 <= rtol * abs_terms + 1e-30).all(), "weighted channel beyond atol scaled by sum|terms|"
+
+
+CAMERAS = [
+    ("identity", np.eye(3), np.zeros(3), 200.0),
+    ("zoom_rot", None, np.array([1.5, -2.0, 0.25]), 35.0),
+    ("wide", None, np.zeros(3), 900.0),
+]
+
+
+def _rot(a, b):
+    ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
+    rx = np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]])
+    ry = np.array([[1, 0, 0], [0, cb, -sb], [0, sb, cb]])
+    return rx @ ry
+
+
+@pytest.mark.parametrize("pipe", ["generic", "default"])
+@pytest.mark.parametrize("cam", CAMERAS, ids=[c[0] for c in CAMERAS])
+@pytest.mark.parametrize("R", [200, 1024])
+def test_weighted_matches_oracle(native, mips, cam, R, pipe):
+    from oracle import oracle_np
+    name, rot, off, scale = cam
+    rot = _rot(0.3, -0.7) if rot is None else rot
+    M, sf = oracle_np.transform_matrix(rot, off, scale)
+    pos, h, m, q, _ = make_cloud(20000, seed=3)
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+    ctx.upload_quantity(q)
+    flags = native.PIPE_GENERIC if pipe == "generic" else native.PIPE_DEFAULT
+    ctx.render(M, sf, mode=native.MODE_WEIGHTED, flags=flags)
+    got = ctx.read_image()
+    want, _ = oracle_render(pos, h, m, q, None, 0, M, sf, R, mips)
+    check_2ch(got, want, abs_terms_image(pos, h, m, q, M, sf, R, mips), rtol=3e-5 if pipe == "generic" else 1e-5)
+    # density-only (q = NULL): channel 1 must be exactly zero
+    ctx.upload_quantity(None)
+    ctx.render(M, sf, mode=native.MODE_WEIGHTED, flags=flags)
+    got = ctx.read_image()
+    assert (got[..., 1] == 0).all()
+    assert np.allclose(got[..., 0], want[..., 0], rtol=3e-5 if pipe == "generic" else 1e-5, atol=0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("pipe", ["generic", "default"])
+def test_rgb_and_depth_match_oracle(native, mips, pipe):
+    from oracle import oracle_np
+    R = 256
+    M, sf = oracle_np.transform_matrix(_rot(0.1, 0.2), np.zeros(3), 120.0)
+    pos, h, m, q, rgb = make_cloud(8000, seed=5)
+    flags = native.PIPE_GENERIC if pipe == "generic" else native.PIPE_DEFAULT
+    ctx = native.Context(R, 4)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, None)
+    ctx.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
+    ctx.render(M, sf, mode=native.MODE_RGB, flags=flags)
+    got = ctx.read_image()
+    want, _ = oracle_render(pos, h, rgb[:, 0].copy(), rgb[:, 1].copy(), rgb[:, 2].copy(), 2, M, sf, R, mips)
+    assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=0)
+    assert np.array_equal(got[..., 3], want[..., 3]), "fragment-count channel must be exact"
+    ctx.close()
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+    ctx.render(M, sf, mode=native.MODE_DEPTH, flags=flags)
+    got = ctx.read_image()
+    want, _ = oracle_render(pos, h, m, None, None, 1, M, sf, R, mips)
+    assert np.allclose(got, want, rtol=1e-5, atol=0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("pipe", ["generic", "default"])
+def test_ranges_and_accumulate(native, mips, pipe):
+    """(start, len) blocks as the reference's indirect draws: clear on the first block only."""
+    from oracle import oracle_np
+    R = 128
+    M, sf = oracle_np.transform_matrix(np.eye(3), np.zeros(3), 150.0)
+    pos, h, m, q, _ = make_cloud(5000, seed=9)
+    flags = native.PIPE_GENERIC if pipe == "generic" else native.PIPE_DEFAULT
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+    ctx.upload_quantity(q)
+    starts = np.array([10, 700, 2500, 4990, 6000, -5]); lens = np.array([300, 1, 1700, 50, 10, 3])
+    ctx.render(M, sf, starts, lens, clear=True, flags=flags)
+    got = ctx.read_image()
+    cs = np.array([10, 700, 2500, 4990]); cl = np.array([300, 1, 1700, 10])
+    want, _ = oracle_render(pos, h, m, q, None, 0, M, sf, R, mips, ranges=(cs, cl))
+    at = abs_terms_image(pos, h, m, q, M, sf, R, mips)
+    check_2ch(got, want, at)
+    # second block without clearing adds on top
+    ctx.render(M, sf, np.array([0]), np.array([10]), clear=False, flags=flags)
+    got2 = ctx.read_image()
+    want2, _ = oracle_render(pos, h, m, q, None, 0, M, sf, R, mips,
+                             ranges=(np.array([0, 10, 700, 2500, 4990]), np.array([10, 300, 1, 1700, 10])))
+    check_2ch(got2, want2, at, rtol=2e-5)
+    # empty selection: clear only
+    ctx.render(M, sf, np.array([], dtype=np.int64), np.array([], dtype=np.int64), clear=True, flags=flags)
+    assert (ctx.read_image() == 0).all()
+    ctx.close()
+
+
+def test_edge_cases(native, mips):
+    from oracle import oracle_np
+    R = 64
+    M, sf = oracle_np.transform_matrix(np.eye(3), np.zeros(3), 10.0)
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    # zero particles
+    e = np.zeros(0, dtype=np.float32)
+    ctx.upload_particles(e, e, e, e, e)
+    ctx.render(M, sf)
+    assert (ctx.read_image() == 0).all()
+    # NaN / inf / zero / negative smoothing, out-of-slab z, off-screen: nothing drawn, nothing crashes
+    x = np.array([0, 0, 0, 0, 0, 1e6, np.nan, 0, 0.3], dtype=np.float32)
+    y = np.zeros_like(x)
+    z = np.array([0, 0, 0, 0, 50, 0, 0, np.inf, 0], dtype=np.float32)
+    h = np.array([np.nan, np.inf, 0, -1, 1, 1, 1, 1, 0.7], dtype=np.float32)
+    m = np.ones_like(x)
+    ctx.upload_particles(x, y, z, h, m)
+    ctx.render(M, sf)
+    got = ctx.read_image()
+    pos = np.stack([x, y, z], axis=1)
+    want, _ = oracle_render(pos, h, m, None, None, 0, M, sf, R, mips)
+    assert np.isfinite(got).all()
+    assert np.allclose(got, want, rtol=1e-5, atol=0)
+    assert got[..., 0].sum() > 0      # the last particle is the only one drawn
+    ctx.close()
+
+
+def test_errors(native, mips):
+    ctx = native.Context(32, 2)
+    x = np.zeros(4, dtype=np.float32)
+    ctx.upload_particles(x, x, x, x + 1, x + 1)
+    with pytest.raises(native.BackendError, match="tsp_set_kernel_mips"):
+        ctx.render(np.eye(4), 1.0)
+    ctx.set_kernel_mips(mips)
+    with pytest.raises(native.BackendError):
+        ctx.render(np.eye(4), 1.0, mode=native.MODE_RGB)      # 2-channel context
+    with pytest.raises(native.BackendError):
+        native.Context(32, 3)
+    with pytest.raises(ValueError):
+        ctx.upload_quantity(np.zeros(3, dtype=np.float32))
+    ctx.close()
+
+
+def test_colormap_bit_exact(native, mips, golden):
+    """kernel B / B' vs the oracle on the identical float buffer: uint8 must match bit-for-bit."""
+    from oracle import oracle_c, oracle_np
+    R = 200
+    d = golden["testdata_n1000.npz"]
+    luts = golden["colormap_luts.npz"]
+    ps, m, q = d["pos_smooth"], d["mass"], d["qty"]
+    M, sf = oracle_np.transform_matrix(np.eye(3), np.zeros(3), 200.0)
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(ps[:, 0], ps[:, 1], ps[:, 2], ps[:, 3], m)
+    ctx.upload_quantity(q)
+    ctx.render(M, sf)
+    img = ctx.read_image()
+    cases = [(True, False, -12.8, -8.2), (False, False, 0.0, 2e-9), (True, True, -6.0, -4.0), (False, True, -1e-4, 1e-4)]
+    for name in ("twilight_shifted", "viridis"):
+        for log, weighted, vmin, vmax in cases:
+            got = ctx.colormap_scalar(luts[name], vmin, vmax, log, weighted)
+            want = oracle_c.colormap_scalar(img, luts[name], vmin, vmax, log, weighted)
+            assert np.array_equal(got, want), (name, log, weighted)
+            got_h = ctx.colormap_scalar_host(img, luts[name], vmin, vmax, log, weighted)
+            assert np.array_equal(got_h, want)
+    # special values: zeros (log -> -inf -> t=0), 0/0 (NaN -> t=0), negatives, inf, denormals
+    rs = np.random.RandomState(0)
+    sp = np.zeros((R, R, 2), dtype=np.float32)
+    sp[..., 0] = np.exp(rs.uniform(-90, 80, size=(R, R)))
+    sp[..., 1] = rs.normal(size=(R, R)) * sp[..., 0]
+    sp[0, :50] = 0.0
+    sp[1, :50, 0] = -1.0
+    sp[2, :50, 0] = np.inf
+    sp[3, :50, 0] = 1e-42
+    sp[4, :50] = np.nan
+    ctx.write_image(sp)
+    for log, weighted, vmin, vmax in [(True, False, -30, 30), (False, False, 0, 1), (True, True, -3, 1), (False, True, -2, 2)]:
+        got = ctx.colormap_scalar(luts["viridis"], vmin, vmax, log, weighted)
+        want = oracle_c.colormap_scalar(sp, luts["viridis"], vmin, vmax, log, weighted)
+        assert np.array_equal(got, want), (log, weighted)
+    ctx.close()
+    # rgb map
+    ctx = native.Context(R, 4)
+    rgb4 = np.zeros((R, R, 4), dtype=np.float32)
+    rgb4[..., :3] = np.exp(rs.uniform(-20, 5, size=(R, R, 3)))
+    rgb4[0, :20, :3] = 0
+    rgb4[1, :20, 0] = np.nan
+    ctx.write_image(rgb4)
+    for gamma in (1.0, 0.5, 2.2):
+        got = ctx.colormap_rgb(-6.0, -1.0, gamma)
+        want = oracle_c.colormap_rgb(rgb4, -6.0, -1.0, gamma)
+        assert np.array_equal(got, want), gamma
+        gf = ctx.colormap_rgb(-6.0, -1.0, gamma, as_float=True)
+        wf = oracle_c.colormap_rgb(rgb4, -6.0, -1.0, gamma, as_float=True)
+        assert np.array_equal(gf, wf, equal_nan=True), gamma
+        assert np.array_equal(ctx.colormap_rgb_host(rgb4, -6.0, -1.0, gamma), want)
+    ctx.close()
+
+
+def test_reference_kats_through_hip(native, mips, golden):
+    """The reference's own golden vectors (tests/test_render_output.py) at its own tolerances, HIP path."""
+    from oracle import oracle_np
+    kats = golden["reference_kats.npz"]
+    cams = golden["cameras.npz"]
+    d = golden["testdata_n1000.npz"]
+    ps, m, q = d["pos_smooth"], d["mass"], d["qty"]
+    R = 200
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(ps[:, 0], ps[:, 1], ps[:, 2], ps[:, 3], m)
+
+    def cam(name):
+        return cams[name + ".transform"].T.copy(), float(cams[name + ".scale_factor"][0])
+    M, sf = cam("identity_200")
+    ctx.render(M, sf)
+    test = ctx.read_image()[::20, ::20, 0].ravel()
+    expect = kats["test_sph_output.expect"]
+    np.testing.assert_allclose(test, expect, rtol=5e-1)           # reference :237
+    assert abs((test / expect).mean() - 1.0) < 0.0015             # reference :240
+    assert (test / expect).std() < 0.015                          # reference :241
+    ctx.upload_quantity(q)
+    M, sf = cam("rot0_0p4_20")
+    ctx.render(M, sf)
+    im = ctx.read_image()
+    np.testing.assert_allclose((im[..., 1] / im[..., 0])[::20, ::20].ravel(),
+                               kats["test_sph_weighted_output.expect"], atol=1.5e-7)   # reference :198
+    M, sf = cam("rot0_0p5_20")
+    ctx.render(M, sf)
+    im = ctx.read_image()
+    np.testing.assert_allclose(im[::20, ::20, 0].ravel(), kats["test_bivariate_render.expect_den"], rtol=2e-3)
+    np.testing.assert_allclose((im[..., 1] / im[..., 0])[::20, ::20].ravel(),
+                               kats["test_bivariate_render.expect_qty"], atol=1e-4)
+    ctx.close()

@@ -1,0 +1,179 @@
+"""The reference's own render tests (tests/test_render_output.py, test_render_mode.py,
+test_colormap.py) restated against the topsy_amd Visualizer on the GPU, with its golden vectors
+and its tolerances."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+import topsy_amd
+from topsy_amd.drawreason import DrawReason
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[False, True], ids=["plain", "with_cells"])
+def vis(request):
+    v = topsy_amd.test(1000, render_resolution=200, with_cells=request.param)
+    v.scale = 200.0
+    yield v
+    v.close()
+
+
+@pytest.fixture(scope="module")
+def kats(golden):
+    return golden["reference_kats.npz"]
+
+
+def test_render(vis, kats):                       # reference test_render :27-65
+    result = vis.get_sph_presentation_image()
+    assert result.dtype == np.uint8 and result.shape == (200, 200, 4)
+    npt.assert_allclose(result[::20, ::20].ravel().astype(int), kats["test_render.reference_result"], atol=5)
+
+
+def test_hdr_rgb_render(kats):                    # reference test_hdr_rgb_render :69-141
+    v = topsy_amd.test(1000, render_resolution=200, render_mode="rgb-hdr")
+    v.scale = 20.0
+    v.colormap.update_parameters({"min_mag": 38.0, "max_mag": 40.0})
+    result = v.get_sph_presentation_image()[..., :3]
+    assert result.dtype == np.float16
+    npt.assert_allclose(result[::20, ::20].ravel().astype(np.float64), kats["test_hdr_rgb_render.result_ref"], atol=1e-2)
+    v.close()
+
+
+def test_particle_pos_smooth(vis):                # reference :144-159
+    if hasattr(vis.data_loader, "_cell_layout"):
+        return
+    npt.assert_allclose(vis.data_loader.get_pos_smooth()[::100][:2],
+                        [[1.6189760e+01, -4.0728635e-01, -1.8409515e+01, 2.0848181e+01],
+                         [-3.6236227e-01, 1.9854842e-02, -3.4908600e+00, 1.2997785e+00]], rtol=1e-7)
+
+
+def test_sph_weighted_output(vis, kats):          # reference :161-198
+    vis.quantity_name = "test-quantity"
+    vis.scale = 20.0
+    vis.rotate(0.0, 0.4)
+    vis.render_sph(DrawReason.EXPORT)
+    result = vis.get_sph_image()
+    assert result.shape == (200, 200)
+    npt.assert_allclose(result[::20, ::20].flatten(), kats["test_sph_weighted_output.expect"], atol=1.5e-7)
+
+
+def test_sph_output(vis, kats):                   # reference :200-241
+    vis.render_sph(DrawReason.EXPORT)
+    result = vis.get_sph_image()
+    assert result.shape == (200, 200)
+    test, expect = result[::20, ::20].flatten(), kats["test_sph_output.expect"]
+    npt.assert_allclose(test, expect, rtol=5e-1)
+    assert abs((test / expect).mean() - 1.0) < 0.0015
+    assert (test / expect).std() < 0.015
+
+
+def test_rotated_sph_output(vis):                 # reference :280-293
+    vis.draw(reason=DrawReason.EXPORT)
+    unrotated = vis.get_sph_image()
+    vis.rotation_matrix = np.array([[0.0, 1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, 1.0]], dtype=np.float32)
+    vis.draw(reason=DrawReason.EXPORT)
+    npt.assert_allclose(unrotated.T[:, ::-1], vis.get_sph_image(), rtol=5e-2)
+
+
+def test_rgb_sph_output():                        # reference :296-300
+    v = topsy_amd.test(1000, render_resolution=200, render_mode="rgb")
+    assert v.get_sph_image().shape == (200, 200, 3)
+    assert v._sph.get_image().shape == (200, 200, 4)
+    v.close()
+
+
+def test_depth_output(kats):                      # reference :302-343
+    v = topsy_amd.test(1000, render_resolution=200)
+    v.scale = 20.0
+    v.rotation_matrix = np.array([[1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [0.0, -1.0, 0.0]], dtype=np.float32)
+    v.render_sph(DrawReason.EXPORT)
+    before = v.get_sph_image().copy()
+    result = v._sph.get_depth_image(DrawReason.EXPORT)
+    npt.assert_allclose(result[::20, ::20].ravel(), kats["test_depth_output.expect"], atol=1e-1)
+    # the depth pass used the shared render target: the next read re-renders the scene itself
+    npt.assert_allclose(v.get_sph_image(), before, rtol=1e-5)
+    v.close()
+
+
+def test_bivariate_splat_values(kats):            # reference test_bivariate_render :345-446 (splat part)
+    v = topsy_amd.test(1000, render_resolution=200)
+    v.quantity_name = "test-quantity"
+    v.scale = 20.0
+    v.rotate(0.0, 0.5)
+    v.render_sph(DrawReason.EXPORT)
+    raw = v._sph.get_image()
+    npt.assert_allclose(raw[::20, ::20, 0].ravel(), kats["test_bivariate_render.expect_den"], rtol=2e-3)
+    npt.assert_allclose(v.get_sph_image()[::20, ::20].ravel(), kats["test_bivariate_render.expect_qty"], atol=1e-4)
+    v.close()
+
+
+def test_render_mode_switching_and_errors():      # reference tests/test_render_mode.py
+    v = topsy_amd.test(1000, render_resolution=64)
+    v.scale = 20.0
+    for mode in ("univariate", "rgb", "rgb-hdr", "univariate"):
+        v.render_mode = mode
+        result, pres = v.get_sph_image(), v.get_sph_presentation_image()
+        assert pres.dtype == (np.float16 if mode.endswith("hdr") else np.uint8) and pres.shape == (64, 64, 4)
+        assert result.shape == ((64, 64, 3) if mode.startswith("rgb") else (64, 64))
+    with pytest.raises(ValueError, match="Invalid render_mode 'invalid'"):
+        v.render_mode = "invalid"
+    assert v.render_mode == "univariate"
+    with pytest.raises(ValueError):
+        v.render_mode = "surface"
+    assert v.render_mode == "univariate"
+    with pytest.raises(ValueError, match="Unable to get quantity"):
+        v.quantity_name = "no-such-quantity"
+    v.close()
+
+
+def test_progressive_frames_fold_mass_scale():
+    """CHANGE frame draws a prefix, REFINE frames add the rest without clearing; the colormap sees
+    N/N_drawn (reference sph.py:306-332, implementation.py:427-453, visualizer.py:386-402)."""
+    v = topsy_amd.test(200000, render_resolution=128)
+    v.scale = 100.0
+    full = v._sph.get_image().copy()
+    rp = v._sph._render_progression
+    rp._recommended_num_particles_to_render = 50000
+    v.invalidate()
+    v.draw(DrawReason.CHANGE)
+    assert v._sph.last_render_mass_scale == pytest.approx(4.0, rel=1e-3)
+    partial = v._sph.get_image()             # scaled by N/N_drawn
+    ratio = partial[..., 0].sum() / full[..., 0].sum()
+    assert 0.97 < ratio < 1.03
+    assert v._pending_draw == DrawReason.REFINE
+    while v._sph.needs_refine():
+        v.draw(DrawReason.REFINE)
+    assert v._sph.last_render_mass_scale == 1.0
+    npt.assert_allclose(v._sph.get_image()[..., 0], full[..., 0], rtol=2e-5, atol=1e-20)
+    v.draw(DrawReason.PRESENTATION_CHANGE)
+    v.close()
+
+
+@pytest.mark.parametrize("mode", ["density", "weighted-average"])
+@pytest.mark.parametrize("log_scale", [True, False], ids=["log", "linear"])
+def test_colormap_vs_matplotlib(mode, log_scale):  # reference tests/test_colormap.py:35-105
+    from matplotlib import colors, cm
+    import matplotlib
+    v = topsy_amd.test(100, render_resolution=200)
+    img = np.empty((200, 200, 2), dtype=np.float32)
+    img[:, :, 0] = np.logspace(-3, 0, 200)
+    img[:, :, 1] = np.linspace(0, 1, 200)[:, np.newaxis] * img[:, :, 0]
+    weighted = mode == "weighted-average"
+    vmin, vmax = ((-2.0 if weighted else -3.0), 0.0) if log_scale else (0.0, 1.0)
+    v.colormap.update_parameters({"type": "density", "weighted_average": weighted, "vmin": vmin, "vmax": vmax,
+                                  "log": log_scale})
+    image = v.colormap.sph_raw_output_to_image(img)
+    assert image.shape == (200, 200, 4) and image.dtype == np.uint8
+    content = v.colormap.sph_raw_output_to_content(img)
+    with np.errstate(divide="ignore"):
+        content = np.log10(content) if log_scale else content
+    mpl = cm.ScalarMappable(norm=colors.Normalize(vmin=vmin, vmax=vmax),
+                            cmap=matplotlib.colormaps[v.colormap.get_parameter("colormap_name")])
+    npt.assert_allclose(image.astype(int), (mpl.to_rgba(content) * 255).astype(np.uint8).astype(int), atol=5)
+    v.close()
+
+
+def test_smoke_entry():
+    import __graft_entry__
+    __graft_entry__.smoke()

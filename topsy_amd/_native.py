@@ -1,0 +1,302 @@
+"""ctypes binding of libtopsy_splat.so -- the only route from the Python host layer to the GPU.
+
+There is deliberately NO fallback: if the HIP library is missing or no GPU is present the
+product raises `BackendUnavailable` (the CPU oracle under oracle/ is test infrastructure and is
+never imported from here).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtopsy_splat.so")
+
+MODE_WEIGHTED, MODE_DEPTH, MODE_RGB = 0, 1, 2
+PIPE_DEFAULT, PIPE_GENERIC = 0, 1
+UNIQUE_ID_BYTES = 128
+
+
+class BackendUnavailable(RuntimeError):
+    """libtopsy_splat.so could not be loaded, or no MI355X-class GPU is visible."""
+
+
+class BackendError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("n_particles", ctypes.c_int64), ("n_small", ctypes.c_int64), ("n_mid", ctypes.c_int64),
+                ("n_huge", ctypes.c_int64), ("n_culled", ctypes.c_int64), ("n_fragments", ctypes.c_int64),
+                ("ms_stream", ctypes.c_double), ("ms_mid", ctypes.c_double), ("ms_huge", ctypes.c_double),
+                ("ms_total", ctypes.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_fp = ctypes.POINTER(ctypes.c_float)
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_ctx = ctypes.c_void_p
+
+# name -> (restype, argtypes); every symbol declared in include/topsy_splat.h
+SIGNATURES = {
+    "tsp_last_error": (ctypes.c_char_p, []),
+    "tsp_version": (ctypes.c_int, []),
+    "tsp_device_count": (ctypes.c_int, []),
+    "tsp_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_ctx)]),
+    "tsp_destroy": (None, [_ctx]),
+    "tsp_set_kernel_mips": (ctypes.c_int, [_ctx, _fp, ctypes.c_int, ctypes.c_int]),
+    "tsp_upload_particles": (ctypes.c_int, [_ctx, ctypes.c_int64, _fp, _fp, _fp, _fp, _fp]),
+    "tsp_upload_quantity": (ctypes.c_int, [_ctx, _fp]),
+    "tsp_upload_rgb": (ctypes.c_int, [_ctx, _fp, _fp, _fp]),
+    "tsp_generate_synthetic": (ctypes.c_int, [_ctx, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64,
+                                              ctypes.c_float, ctypes.c_int, ctypes.c_int]),
+    "tsp_reorder_spatial": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_uint64, _i64p]),
+    "tsp_download_particles": (ctypes.c_int, [_ctx] + [_fp] * 9),
+    "tsp_num_particles": (ctypes.c_int64, [_ctx]),
+    "tsp_render": (ctypes.c_int, [_ctx, _fp, ctypes.c_float, _i64p, _i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    "tsp_read_image": (ctypes.c_int, [_ctx, _fp]),
+    "tsp_write_image": (ctypes.c_int, [_ctx, _fp]),
+    "tsp_colormap_scalar": (ctypes.c_int, [_ctx, _fp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                           ctypes.c_int, _u8p]),
+    "tsp_colormap_rgb": (ctypes.c_int, [_ctx, ctypes.c_float, ctypes.c_float, ctypes.c_float, _u8p, _fp]),
+    "tsp_colormap_scalar_host": (ctypes.c_int, [_ctx, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int,
+                                                ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _u8p]),
+    "tsp_colormap_rgb_host": (ctypes.c_int, [_ctx, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                             ctypes.c_float, ctypes.c_float, _u8p, _fp]),
+    "tsp_get_stats": (ctypes.c_int, [_ctx, ctypes.POINTER(Stats)]),
+    "tsp_set_option": (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.c_int64]),
+    "tsp_measure_read_bandwidth": (ctypes.c_int, [_ctx, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    "tsp_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "tsp_comm_init": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
+    "tsp_comm_reduce_image": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    "tsp_comm_destroy": (ctypes.c_int, [_ctx]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libtopsy_splat.so and declare every prototype. Raises BackendUnavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendUnavailable(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C topsy_amd/csrc` (needs hipcc, --offload-arch=gfx950)")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise BackendUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise BackendUnavailable(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise BackendError(f"libtopsy_splat error {rc}: {load_library().tsp_last_error().decode(errors='replace')}")
+    return rc
+
+
+def _f32(a, n=None, name="array"):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if n is not None and a.size != n:
+        raise ValueError(f"{name} has {a.size} elements, expected {n}")
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_fp)
+
+
+def device_count():
+    return load_library().tsp_device_count()
+
+
+class Context:
+    """One GPU renderer: R x R x C float32 target + resident SoA particles (include/topsy_splat.h)."""
+
+    def __init__(self, resolution, n_channels, device_id=0):
+        lib = load_library()
+        ndev = lib.tsp_device_count()
+        if ndev <= 0:
+            raise BackendUnavailable("no HIP device visible: the topsy_amd render path needs an AMD GPU "
+                                     "(there is no CPU fallback)")
+        h = _ctx()
+        _check(lib.tsp_create(int(device_id), int(resolution), int(n_channels), ctypes.byref(h)))
+        self._h = h
+        self._lib = lib
+        self.resolution = int(resolution)
+        self.n_channels = int(n_channels)          # capacity of the render target
+        self.active_channels = int(n_channels)     # layout of the image currently held (2 or 4)
+        self.device_id = int(device_id)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tsp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data -----------------------------------------------------------------------------
+    def set_kernel_mips(self, mips, n0=64, n_levels=4):
+        mips = _f32(mips, name="kernel mips")
+        _check(self._lib.tsp_set_kernel_mips(self._h, _ptr(mips), n0, n_levels))
+
+    def upload_particles(self, x, y, z, h, mass=None):
+        n = len(x)
+        arrs = [_f32(a, n, nm) for a, nm in ((x, "x"), (y, "y"), (z, "z"), (h, "h"))]
+        m = None if mass is None else _f32(mass, n, "mass")
+        _check(self._lib.tsp_upload_particles(self._h, n, *[_ptr(a) for a in arrs], _ptr(m)))
+
+    def upload_quantity(self, q):
+        q = None if q is None else _f32(q, self.num_particles, "quantity")
+        _check(self._lib.tsp_upload_quantity(self._h, _ptr(q)))
+
+    def upload_rgb(self, r, g, b):
+        n = self.num_particles
+        r, g, b = _f32(r, n, "r"), _f32(g, n, "g"), _f32(b, n, "b")
+        _check(self._lib.tsp_upload_rgb(self._h, _ptr(r), _ptr(g), _ptr(b)))
+
+    def generate_synthetic(self, n_total, first=0, count=None, seed=1337, h_cap=0.0, with_quantity=False,
+                           with_rgb=False):
+        count = n_total - first if count is None else count
+        _check(self._lib.tsp_generate_synthetic(self._h, n_total, first, count, seed, h_cap, int(with_quantity),
+                                                int(with_rgb)))
+
+    def reorder_spatial(self, n_strata=1, seed=1337, want_permutation=False):
+        perm = np.empty(self.num_particles, dtype=np.int64) if want_permutation else None
+        _check(self._lib.tsp_reorder_spatial(self._h, n_strata, seed,
+                                             None if perm is None else perm.ctypes.data_as(_i64p)))
+        return perm
+
+    def download_particles(self, names=("x", "y", "z", "h", "mass")):
+        order = ("x", "y", "z", "h", "mass", "q", "r", "g", "b")
+        n = self.num_particles
+        out = {k: np.empty(n, dtype=np.float32) for k in names}
+        _check(self._lib.tsp_download_particles(self._h, *[_ptr(out.get(k)) for k in order]))
+        return out
+
+    @property
+    def num_particles(self):
+        return int(self._lib.tsp_num_particles(self._h))
+
+    # ---- render ---------------------------------------------------------------------------
+    def render(self, matrix, scale_factor, starts=None, lens=None, clear=True, mode=MODE_WEIGHTED, flags=PIPE_DEFAULT):
+        """One synchronous render block; returns GPU milliseconds (hipEvent pair)."""
+        M = _f32(np.asarray(matrix, dtype=np.float32).reshape(16), 16, "matrix")
+        ms = ctypes.c_double(0.0)
+        if starts is None:
+            sp = lp = None
+            nr = 0
+        else:
+            s = np.ascontiguousarray(starts, dtype=np.int64)
+            l = np.ascontiguousarray(lens, dtype=np.int64)
+            if s.shape != l.shape or s.ndim != 1:
+                raise ValueError("starts and lens must be 1-D arrays of equal length")
+            sp, lp, nr = s.ctypes.data_as(_i64p), l.ctypes.data_as(_i64p), len(s)
+        _check(self._lib.tsp_render(self._h, _ptr(M), float(scale_factor), sp, lp, nr, int(bool(clear)), int(mode),
+                                    int(flags), ctypes.byref(ms)))
+        self.active_channels = 4 if mode == MODE_RGB else 2
+        return ms.value
+
+    def read_image(self):
+        out = np.empty((self.resolution, self.resolution, self.active_channels), dtype=np.float32)
+        _check(self._lib.tsp_read_image(self._h, _ptr(out)))
+        return out
+
+    def write_image(self, img):
+        """Overwrite the render target; the last axis (2 or 4) selects the active layout."""
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        if img.shape[:2] != (self.resolution, self.resolution) or img.shape[2] not in (2, 4) or img.shape[2] > self.n_channels:
+            raise ValueError(f"image shape {img.shape} does not fit the render target")
+        self.set_option("active_channels", img.shape[2])
+        self.active_channels = img.shape[2]
+        _check(self._lib.tsp_write_image(self._h, _ptr(img)))
+
+    def stats(self):
+        s = Stats()
+        _check(self._lib.tsp_get_stats(self._h, ctypes.byref(s)))
+        return s.as_dict()
+
+    def set_option(self, name, value):
+        _check(self._lib.tsp_set_option(self._h, name.encode(), int(value)))
+
+    def measure_read_bandwidth(self, nbytes=1 << 30, iters=10):
+        g = ctypes.c_double(0.0)
+        _check(self._lib.tsp_measure_read_bandwidth(self._h, nbytes, iters, ctypes.byref(g)))
+        return g.value
+
+    # ---- colormap -------------------------------------------------------------------------
+    def colormap_scalar(self, lut_rgba, vmin, vmax, log, weighted):
+        lut = _f32(lut_rgba, name="lut")
+        out = np.empty((self.resolution, self.resolution, 4), dtype=np.uint8)
+        _check(self._lib.tsp_colormap_scalar(self._h, _ptr(lut), lut.size // 4, float(vmin), float(vmax), int(bool(log)),
+                                             int(bool(weighted)), out.ctypes.data_as(_u8p)))
+        return out
+
+    def colormap_rgb(self, vmin, vmax, gamma, as_float=False):
+        shape = (self.resolution, self.resolution, 4)
+        if as_float:
+            out = np.empty(shape, dtype=np.float32)
+            _check(self._lib.tsp_colormap_rgb(self._h, float(vmin), float(vmax), float(gamma), None, _ptr(out)))
+        else:
+            out = np.empty(shape, dtype=np.uint8)
+            _check(self._lib.tsp_colormap_rgb(self._h, float(vmin), float(vmax), float(gamma),
+                                              out.ctypes.data_as(_u8p), None))
+        return out
+
+    def colormap_scalar_host(self, img, lut_rgba, vmin, vmax, log, weighted):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        H, W, C = img.shape
+        lut = _f32(lut_rgba, name="lut")
+        out = np.empty((H, W, 4), dtype=np.uint8)
+        _check(self._lib.tsp_colormap_scalar_host(self._h, _ptr(img), H, W, C, _ptr(lut), lut.size // 4, float(vmin),
+                                                  float(vmax), int(bool(log)), int(bool(weighted)),
+                                                  out.ctypes.data_as(_u8p)))
+        return out
+
+    def colormap_rgb_host(self, img, vmin, vmax, gamma, as_float=False):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        H, W, C = img.shape
+        if as_float:
+            out = np.empty((H, W, 4), dtype=np.float32)
+            _check(self._lib.tsp_colormap_rgb_host(self._h, _ptr(img), H, W, C, float(vmin), float(vmax), float(gamma),
+                                                   None, _ptr(out)))
+        else:
+            out = np.empty((H, W, 4), dtype=np.uint8)
+            _check(self._lib.tsp_colormap_rgb_host(self._h, _ptr(img), H, W, C, float(vmin), float(vmax), float(gamma),
+                                                   out.ctypes.data_as(_u8p), None))
+        return out
+
+    # ---- multi-GPU ------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+        _check(load_library().tsp_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, n_ranks, rank, unique_id):
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        _check(self._lib.tsp_comm_init(self._h, n_ranks, rank, unique_id))
+
+    def comm_reduce_image(self, root=0):
+        ms = ctypes.c_double(0.0)
+        _check(self._lib.tsp_comm_reduce_image(self._h, root, ctypes.byref(ms)))
+        return ms.value

@@ -1,0 +1,83 @@
+"""ColormapHolder: owns the currently active colormap implementation and swaps it when a parameter
+update asks for a different kind (mirror of reference src/topsy/colormap/__init__.py:12-159)."""
+import numpy as np
+
+from .. import config
+from .implementation import ColormapBase, NoColormap, Colormap, RGBColormap, RGBHDRColormap
+
+
+def _all_subclasses(base):
+    for sub in base.__subclasses__():
+        yield sub
+        yield from _all_subclasses(sub)
+
+
+class ColormapHolder:
+    def __init__(self, device, input_texture, output_format):
+        self._device = device
+        self._input_texture = input_texture
+        self._output_format = output_format
+        self._impl = self.instance_from_parameters(
+            {"colormap_name": config.DEFAULT_COLORMAP, "vmin": None, "vmax": None, "log": False, "type": "none"},
+            device, input_texture, output_format)
+
+    def _check_valid(self):
+        if self._impl is None or isinstance(self._impl, NoColormap):
+            raise ValueError("ColormapHolder is not fully initialized")
+
+    @classmethod
+    def _class_from_parameters(cls, parameters):
+        for candidate in _all_subclasses(ColormapBase):
+            if candidate.accepts_parameters(parameters):
+                return candidate
+        return None
+
+    @classmethod
+    def instance_from_parameters(cls, parameters, device, input_texture, output_format):
+        chosen = cls._class_from_parameters(parameters)
+        if chosen is None:
+            raise ValueError(f"No colormap class found for parameters: {parameters}")
+        return chosen(device, input_texture, output_format, parameters)
+
+    def update_parameters(self, parameters):
+        """Returns True when a new implementation object had to be created."""
+        merged = self.get_parameters() | parameters
+        if self._impl is None and self._class_from_parameters(merged) is None:
+            return None
+        if self._impl is None or not self._impl.accepts_parameters(merged):
+            self._impl = self.instance_from_parameters(merged, self._device, self._input_texture, self._output_format)
+            return True
+        self._impl.update_parameters(parameters)
+        return False
+
+    def get_parameter(self, name):
+        return self._impl.get_parameter(name)
+
+    def get_parameters(self):
+        return self._impl.get_parameters()
+
+    def autorange(self, sph_render_output: np.ndarray):
+        self._check_valid()
+        self._impl.autorange_vmin_vmax(sph_render_output)
+
+    def encode_render_pass(self, command_encoder, target_texture_view):
+        self._check_valid()
+        return self._impl.encode_render_pass(command_encoder, target_texture_view)
+
+    def set_scaling(self, width, height, mass_scaling):
+        self._check_valid()
+        self._impl.set_scaling(width, height, mass_scaling)
+
+    def sph_raw_output_to_image(self, sph_raw_output):
+        self._check_valid()
+        return self._impl.sph_raw_output_to_image(sph_raw_output)
+
+    def sph_raw_output_to_content(self, sph_raw_output):
+        self._check_valid()
+        return self._impl.sph_raw_output_to_content(sph_raw_output)
+
+    def __getitem__(self, key):
+        return self.get_parameter(key)
+
+    def __setitem__(self, key, value):
+        self.update_parameters({key: value})

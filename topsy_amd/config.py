@@ -1,0 +1,18 @@
+"""Constants of the render path.  Values are the reference's (src/topsy/config.py:1-44) so that
+time-budgeted progressive rendering and the colormap LUT behave identically."""
+
+DEFAULT_RESOLUTION = 1024            # config.py:1
+DEFAULT_COLORMAP = "twilight_shifted"  # config.py:2
+DEFAULT_SCALE = 200.0                # config.py:4  half-width of the view, kpc
+TARGET_FPS = 30                      # config.py:6
+INITIAL_PARTICLES_TO_RENDER = 1e5    # config.py:7
+COLORMAP_NUM_SAMPLES = 1000          # config.py:14
+TEST_DATA_NUM_PARTICLES_DEFAULT = int(1e6)   # config.py:16
+MAX_PARTICLES_PER_EXPORT_RENDERCALL = 2 ** 25  # config.py:22
+DEFAULT_CELLS_NSIDE = 16             # config.py:27
+CELL_LAYOUT_FRACTIONAL_PADDING = 1e-5  # config.py:33
+
+# --- backend-specific knobs (no reference counterpart) -------------------------------------
+# number of uniform random strata used by the load-time spatial ordering (tsp_reorder_spatial):
+# index prefixes stay unbiased samples at 1/STRATA granularity while runs stay screen-coherent.
+SPATIAL_ORDER_STRATA = 32

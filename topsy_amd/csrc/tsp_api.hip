@@ -1,0 +1,464 @@
+// tsp_api.hip -- the extern "C" boundary of libtopsy_splat (see include/topsy_splat.h).
+//
+// Each entry point cites the reference interface it replaces in the header.  Everything here is
+// host-side plumbing: argument validation, HBM allocation, uploads, kernel dispatch, hipEvent
+// timing (the TimeGpuOperation hook of reference src/topsy/util.py:76-115) and read-back.
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "tsp_internal.h"
+
+namespace tsp {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ensure_array(float **p, int64_t n) {
+    if (*p) {
+        TSP_HIP(hipFree(*p));
+        *p = nullptr;
+    }
+    if (n > 0) TSP_HIP(hipMalloc((void **)p, (size_t)n * sizeof(float)));
+    return TSP_OK;
+}
+
+static int upload_array(tsp_context *ctx, float **dst, const float *src, int64_t n) {
+    if (!*dst) TSP_HIP(hipMalloc((void **)dst, (size_t)n * sizeof(float)));
+    TSP_HIP(hipMemcpyAsync(*dst, src, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return TSP_OK;
+}
+
+__global__ void gather_kernel(const float *__restrict__ src, const uint32_t *__restrict__ perm, float *__restrict__ dst,
+                              int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[perm[i]];
+}
+
+// upload in caller order, then apply the load-time permutation if one is active
+static int upload_permuted(tsp_context *ctx, float **dst, const float *src, int64_t n) {
+    if (!ctx->p.perm) return upload_array(ctx, dst, src, n);
+    float *tmp = nullptr;
+    TSP_HIP(hipMalloc((void **)&tmp, (size_t)n * sizeof(float)));
+    TSP_HIP(hipMemcpyAsync(tmp, src, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (!*dst) TSP_HIP(hipMalloc((void **)dst, (size_t)n * sizeof(float)));
+    hipLaunchKernelGGL(gather_kernel, dim3(2048), dim3(256), 0, ctx->stream, tmp, ctx->p.perm, *dst, n);
+    TSP_HIP(hipGetLastError());
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    TSP_HIP(hipFree(tmp));
+    return TSP_OK;
+}
+
+static void free_particles(tsp_context *ctx) {
+    Particles &p = ctx->p;
+    float **arrs[] = {&p.x, &p.y, &p.z, &p.h, &p.m, &p.q, &p.r, &p.g, &p.b};
+    for (float **a : arrs) {
+        if (*a) (void)hipFree(*a);
+        *a = nullptr;
+    }
+    if (p.perm) (void)hipFree(p.perm);
+    p.perm = nullptr;
+    p.n = 0;
+}
+
+}  // namespace tsp
+
+using namespace tsp;
+
+extern "C" {
+
+const char *tsp_last_error(void) { return g_err; }
+int tsp_version(void) { return 100; }
+
+int tsp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        set_error("hipGetDeviceCount failed");
+        return TSP_ENODEV;
+    }
+    return n;
+}
+
+int tsp_create(int device_id, int resolution, int n_channels, tsp_context **out) {
+    TSP_REQUIRE(out != nullptr, TSP_EINVAL, "out is NULL");
+    *out = nullptr;
+    TSP_REQUIRE(resolution > 0 && resolution <= 16384, TSP_EINVAL, "resolution %d out of range", resolution);
+    TSP_REQUIRE(n_channels == 2 || n_channels == 4, TSP_EINVAL, "n_channels must be 2 (SPH) or 4 (RGBSPH), got %d",
+                n_channels);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available");
+        return TSP_ENODEV;
+    }
+    TSP_REQUIRE(device_id >= 0 && device_id < ndev, TSP_ENODEV, "device %d not present (%d devices)", device_id, ndev);
+    TSP_HIP(hipSetDevice(device_id));
+    tsp_context *ctx = new tsp_context();
+    ctx->device = device_id;
+    ctx->R = resolution;
+    ctx->C = n_channels;
+    ctx->Ccap = n_channels;
+    hipDeviceProp_t prop;
+    TSP_HIP(hipGetDeviceProperties(&prop, device_id));
+    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    TSP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (auto &e : ctx->ev) TSP_HIP(hipEventCreate(&e));
+    const size_t npx = (size_t)resolution * resolution;
+    TSP_HIP(hipMalloc((void **)&ctx->image, npx * n_channels * sizeof(float)));
+    TSP_HIP(hipMemsetAsync(ctx->image, 0, npx * n_channels * sizeof(float), ctx->stream));
+    TSP_HIP(hipMalloc((void **)&ctx->mips, MIP_TOTAL * sizeof(float)));
+    TSP_HIP(hipMalloc((void **)&ctx->counters, sizeof(Counters)));
+    TSP_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(Counters), ctx->stream));
+    TSP_HIP(hipMalloc((void **)&ctx->out8, npx * 4));
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    *out = ctx;
+    return TSP_OK;
+}
+
+void tsp_destroy(tsp_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    tsp_comm_destroy(ctx);
+    free_particles(ctx);
+    void *ptrs[] = {ctx->image, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->scratch,
+                    ctx->ws.mid_records, ctx->ws.huge_records, ctx->ws.seg_count, ctx->ws.seg_bbox, ctx->ws.range_prefix};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int tsp_set_kernel_mips(tsp_context *ctx, const float *lut, int n0, int n_levels) {
+    TSP_REQUIRE(ctx && lut, TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(n0 == 64 && n_levels == 4, TSP_EINVAL,
+                "kernel texture must be 64^2 with 4 mip levels (reference sph.py:396), got n0=%d levels=%d", n0, n_levels);
+    TSP_HIP(hipSetDevice(ctx->device));
+    TSP_HIP(hipMemcpy(ctx->mips, lut, MIP_TOTAL * sizeof(float), hipMemcpyHostToDevice));
+    ctx->have_mips = true;
+    return TSP_OK;
+}
+
+int tsp_upload_particles(tsp_context *ctx, int64_t n, const float *x, const float *y, const float *z, const float *h,
+                         const float *mass) {
+    TSP_REQUIRE(ctx, TSP_EINVAL, "NULL context");
+    TSP_REQUIRE(n >= 0 && n < ((int64_t)1 << 32), TSP_EINVAL, "particle count %lld out of range", (long long)n);
+    TSP_REQUIRE(n == 0 || (x && y && z && h), TSP_EINVAL, "NULL position/smoothing array");
+    TSP_HIP(hipSetDevice(ctx->device));
+    free_particles(ctx);
+    ctx->p.n = n;
+    if (n == 0) return TSP_OK;
+    int rc;
+    if ((rc = upload_array(ctx, &ctx->p.x, x, n))) return rc;
+    if ((rc = upload_array(ctx, &ctx->p.y, y, n))) return rc;
+    if ((rc = upload_array(ctx, &ctx->p.z, z, n))) return rc;
+    if ((rc = upload_array(ctx, &ctx->p.h, h, n))) return rc;
+    if (mass && (rc = upload_array(ctx, &ctx->p.m, mass, n))) return rc;
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
+int tsp_upload_quantity(tsp_context *ctx, const float *q) {
+    TSP_REQUIRE(ctx, TSP_EINVAL, "NULL context");
+    TSP_HIP(hipSetDevice(ctx->device));
+    if (!q) {
+        if (ctx->p.q) TSP_HIP(hipFree(ctx->p.q));
+        ctx->p.q = nullptr;
+        return TSP_OK;
+    }
+    TSP_REQUIRE(ctx->p.n > 0, TSP_ESTATE, "upload particles before the quantity");
+    int rc = upload_permuted(ctx, &ctx->p.q, q, ctx->p.n);
+    if (rc) return rc;
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
+int tsp_upload_rgb(tsp_context *ctx, const float *r, const float *g, const float *b) {
+    TSP_REQUIRE(ctx && r && g && b, TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(ctx->p.n > 0, TSP_ESTATE, "upload particles before rgb");
+    TSP_HIP(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = upload_permuted(ctx, &ctx->p.r, r, ctx->p.n))) return rc;
+    if ((rc = upload_permuted(ctx, &ctx->p.g, g, ctx->p.n))) return rc;
+    if ((rc = upload_permuted(ctx, &ctx->p.b, b, ctx->p.n))) return rc;
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
+int tsp_generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int64_t count, uint64_t seed, float h_cap,
+                           int with_quantity, int with_rgb) {
+    TSP_REQUIRE(ctx, TSP_EINVAL, "NULL context");
+    TSP_REQUIRE(n_total > 0 && first >= 0 && count >= 0 && first + count <= n_total, TSP_EINVAL,
+                "bad shard [%lld, +%lld) of %lld", (long long)first, (long long)count, (long long)n_total);
+    TSP_REQUIRE(count < ((int64_t)1 << 32), TSP_EINVAL, "shard too large");
+    TSP_HIP(hipSetDevice(ctx->device));
+    free_particles(ctx);
+    return generate_synthetic(ctx, n_total, first, count, seed, h_cap, with_quantity, with_rgb);
+}
+
+int tsp_reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out) {
+    TSP_REQUIRE(ctx, TSP_EINVAL, "NULL context");
+    TSP_REQUIRE(n_strata >= 1 && n_strata <= 4096, TSP_EINVAL, "n_strata %d out of range", n_strata);
+    TSP_REQUIRE(ctx->p.n > 0, TSP_ESTATE, "no particles resident");
+    TSP_HIP(hipSetDevice(ctx->device));
+    return reorder_spatial(ctx, n_strata, seed, perm_out);
+}
+
+int64_t tsp_num_particles(tsp_context *ctx) { return ctx ? ctx->p.n : 0; }
+
+int tsp_download_particles(tsp_context *ctx, float *x, float *y, float *z, float *h, float *mass, float *q, float *r,
+                           float *g, float *b) {
+    TSP_REQUIRE(ctx, TSP_EINVAL, "NULL context");
+    TSP_HIP(hipSetDevice(ctx->device));
+    const Particles &p = ctx->p;
+    struct { float *dst; const float *src; const char *name; } items[] = {
+        {x, p.x, "x"}, {y, p.y, "y"}, {z, p.z, "z"}, {h, p.h, "h"}, {mass, p.m, "mass"},
+        {q, p.q, "q"}, {r, p.r, "r"}, {g, p.g, "g"}, {b, p.b, "b"}};
+    for (auto &it : items) {
+        if (!it.dst) continue;
+        TSP_REQUIRE(it.src, TSP_ESTATE, "array '%s' is not resident", it.name);
+        TSP_HIP(hipMemcpy(it.dst, it.src, (size_t)p.n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return TSP_OK;
+}
+
+int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64_t *starts, const int64_t *lens,
+               int n_ranges, int clear, int mode, int flags, double *gpu_ms_out) {
+    TSP_REQUIRE(ctx && M, TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(ctx->have_mips, TSP_ESTATE, "tsp_set_kernel_mips must be called before tsp_render");
+    TSP_REQUIRE(mode == TSP_MODE_WEIGHTED || mode == TSP_MODE_DEPTH || mode == TSP_MODE_RGB, TSP_EINVAL, "bad mode %d",
+                mode);
+    if (mode == TSP_MODE_RGB) {
+        TSP_REQUIRE(ctx->Ccap == 4, TSP_EINVAL, "TSP_MODE_RGB needs a 4-channel context");
+        TSP_REQUIRE(ctx->p.n == 0 || (ctx->p.r && ctx->p.g && ctx->p.b), TSP_ESTATE, "rgb arrays not uploaded");
+    } else {
+        TSP_REQUIRE(ctx->p.n == 0 || ctx->p.m, TSP_ESTATE, "mass array not uploaded");
+    }
+    // the active channel count follows the mode (a 4-channel context can also hold 2-channel renders);
+    // a block that does not clear must continue in the layout of the image it adds to
+    const int newC = (mode == TSP_MODE_RGB) ? 4 : 2;
+    TSP_REQUIRE(clear || newC == ctx->C, TSP_ESTATE, "cannot accumulate a %d-channel block onto a %d-channel image",
+                newC, ctx->C);
+    ctx->C = newC;
+    TSP_REQUIRE(n_ranges >= 0 && (n_ranges == 0 || (starts && lens) || (!starts && !lens)), TSP_EINVAL, "bad ranges");
+    TSP_HIP(hipSetDevice(ctx->device));
+
+    // clip the ranges to [0, n) and drop empties (an indirect draw with instance_count 0 draws nothing)
+    std::vector<int64_t> s, l;
+    if (!starts) {
+        if (ctx->p.n > 0) { s.push_back(0); l.push_back(ctx->p.n); }
+    } else {
+        for (int i = 0; i < n_ranges; ++i) {
+            int64_t b = starts[i], e = starts[i] + lens[i];
+            if (b < 0) b = 0;
+            if (e > ctx->p.n) e = ctx->p.n;
+            if (e > b) { s.push_back(b); l.push_back(e - b); }
+        }
+    }
+    const int nr = (int)s.size();
+    int64_t total = 0;
+    for (int i = 0; i < nr; ++i) total += l[i];
+
+    Camera cam;
+    for (int i = 0; i < 12; ++i) cam.m[i] = M[i];
+    cam.sf = scale_factor;
+    cam.R = ctx->R;
+    cam.Rf = (float)ctx->R;
+    cam.halfR = 0.5f * cam.Rf;
+
+    TSP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    if (clear)
+        TSP_HIP(hipMemsetAsync(ctx->image, 0, (size_t)ctx->R * ctx->R * ctx->C * sizeof(float), ctx->stream));
+    TSP_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(Counters), ctx->stream));
+    ctx->stats = tsp_stats{};
+    ctx->stats.n_particles = total;
+    int rc = TSP_OK;
+    if (total > 0) {
+        if (flags & TSP_PIPE_GENERIC) {
+            // device copy of the ranges: starts | lens | prefix
+            std::vector<int64_t> pack(3 * (size_t)nr + 1);
+            int64_t acc = 0;
+            for (int i = 0; i < nr; ++i) {
+                pack[i] = s[i];
+                pack[nr + i] = l[i];
+                pack[2 * nr + i] = acc;
+                acc += l[i];
+            }
+            pack[3 * nr] = acc;
+            if (ctx->ws.range_capacity < (int64_t)pack.size()) {
+                if (ctx->ws.range_prefix) TSP_HIP(hipFree(ctx->ws.range_prefix));
+                ctx->ws.range_capacity = (int64_t)pack.size() * 2 + 64;
+                TSP_HIP(hipMalloc((void **)&ctx->ws.range_prefix, ctx->ws.range_capacity * sizeof(int64_t)));
+            }
+            TSP_HIP(hipMemcpyAsync(ctx->ws.range_prefix, pack.data(), pack.size() * sizeof(int64_t),
+                                   hipMemcpyHostToDevice, ctx->stream));
+            rc = launch_generic(ctx, cam, ctx->ws.range_prefix, nr, total, mode);
+            // pack must outlive the async copy
+            TSP_HIP(hipStreamSynchronize(ctx->stream));
+        } else {
+            rc = launch_pipeline(ctx, cam, s.data(), l.data(), nr, total, mode);
+        }
+    }
+    if (rc) return rc;
+    TSP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->stats.ms_total = ms;
+    Counters hc;
+    TSP_HIP(hipMemcpy(&hc, ctx->counters, sizeof(hc), hipMemcpyDeviceToHost));
+    ctx->stats.n_small = (int64_t)hc.n_small;
+    ctx->stats.n_mid = (int64_t)hc.n_mid;
+    ctx->stats.n_huge = (int64_t)hc.n_huge;
+    ctx->stats.n_culled = (int64_t)hc.n_culled;
+    ctx->stats.n_fragments = (int64_t)hc.n_fragments;
+    if (gpu_ms_out) *gpu_ms_out = ms;
+    return TSP_OK;
+}
+
+int tsp_read_image(tsp_context *ctx, float *out) {
+    TSP_REQUIRE(ctx && out, TSP_EINVAL, "NULL argument");
+    TSP_HIP(hipSetDevice(ctx->device));
+    TSP_HIP(hipMemcpy(out, ctx->image, (size_t)ctx->R * ctx->R * ctx->C * sizeof(float), hipMemcpyDeviceToHost));
+    return TSP_OK;
+}
+
+int tsp_write_image(tsp_context *ctx, const float *in) {
+    TSP_REQUIRE(ctx && in, TSP_EINVAL, "NULL argument");
+    TSP_HIP(hipSetDevice(ctx->device));
+    TSP_HIP(hipMemcpy(ctx->image, in, (size_t)ctx->R * ctx->R * ctx->C * sizeof(float), hipMemcpyHostToDevice));
+    return TSP_OK;
+}
+
+static int ensure_lut(tsp_context *ctx, const float *lut_rgba, int n_lut) {
+    TSP_REQUIRE(lut_rgba && n_lut >= 2 && n_lut <= 65536, TSP_EINVAL, "bad colormap LUT (n=%d)", n_lut);
+    if (ctx->lut_capacity < n_lut) {
+        if (ctx->lut) TSP_HIP(hipFree(ctx->lut));
+        TSP_HIP(hipMalloc((void **)&ctx->lut, (size_t)n_lut * 4 * sizeof(float)));
+        ctx->lut_capacity = n_lut;
+    }
+    TSP_HIP(hipMemcpyAsync(ctx->lut, lut_rgba, (size_t)n_lut * 4 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return TSP_OK;
+}
+
+int tsp_colormap_scalar(tsp_context *ctx, const float *lut_rgba, int n_lut, float vmin, float vmax, int log_scale,
+                        int weighted, uint8_t *out_rgba) {
+    TSP_REQUIRE(ctx && out_rgba, TSP_EINVAL, "NULL argument");
+    TSP_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_lut(ctx, lut_rgba, n_lut);
+    if (rc) return rc;
+    const int64_t npix = (int64_t)ctx->R * ctx->R;
+    rc = launch_colormap_scalar(ctx, ctx->image, npix, ctx->C, ctx->lut, n_lut, vmin, vmax, log_scale, weighted, ctx->out8);
+    if (rc) return rc;
+    TSP_HIP(hipMemcpyAsync(out_rgba, ctx->out8, (size_t)npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
+int tsp_colormap_rgb(tsp_context *ctx, float vmin, float vmax, float gamma, uint8_t *out_rgba8, float *out_rgba_f32) {
+    TSP_REQUIRE(ctx && (out_rgba8 || out_rgba_f32), TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(ctx->C == 4, TSP_EINVAL, "rgb colormap needs a 4-channel image");
+    TSP_HIP(hipSetDevice(ctx->device));
+    const int64_t npix = (int64_t)ctx->R * ctx->R;
+    if (out_rgba_f32 && !ctx->outf) TSP_HIP(hipMalloc((void **)&ctx->outf, (size_t)npix * 4 * sizeof(float)));
+    int rc = launch_colormap_rgb(ctx, ctx->image, npix, ctx->C, vmin, vmax, gamma, out_rgba8 ? ctx->out8 : nullptr,
+                                 out_rgba_f32 ? ctx->outf : nullptr);
+    if (rc) return rc;
+    if (out_rgba8) TSP_HIP(hipMemcpyAsync(out_rgba8, ctx->out8, (size_t)npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_rgba_f32)
+        TSP_HIP(hipMemcpyAsync(out_rgba_f32, ctx->outf, (size_t)npix * 16, hipMemcpyDeviceToHost, ctx->stream));
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
+static int ensure_scratch(tsp_context *ctx, size_t bytes) {
+    if (ctx->scratch_bytes < bytes) {
+        if (ctx->scratch) TSP_HIP(hipFree(ctx->scratch));
+        TSP_HIP(hipMalloc(&ctx->scratch, bytes));
+        ctx->scratch_bytes = bytes;
+    }
+    return TSP_OK;
+}
+
+int tsp_colormap_scalar_host(tsp_context *ctx, const float *img, int H, int W, int C, const float *lut_rgba, int n_lut,
+                             float vmin, float vmax, int log_scale, int weighted, uint8_t *out_rgba) {
+    TSP_REQUIRE(ctx && img && out_rgba, TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(H > 0 && W > 0 && C >= 2, TSP_EINVAL, "bad image shape %dx%dx%d", H, W, C);
+    TSP_HIP(hipSetDevice(ctx->device));
+    const int64_t npix = (int64_t)H * W;
+    const size_t in_bytes = (size_t)npix * C * sizeof(float), out_bytes = (size_t)npix * 4;
+    int rc = ensure_scratch(ctx, in_bytes + out_bytes + 256);
+    if (rc) return rc;
+    if ((rc = ensure_lut(ctx, lut_rgba, n_lut))) return rc;
+    float *d_in = (float *)ctx->scratch;
+    uint8_t *d_out = (uint8_t *)ctx->scratch + ((in_bytes + 255) & ~(size_t)255);
+    TSP_HIP(hipMemcpyAsync(d_in, img, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_colormap_scalar(ctx, d_in, npix, C, ctx->lut, n_lut, vmin, vmax, log_scale, weighted, d_out)))
+        return rc;
+    TSP_HIP(hipMemcpyAsync(out_rgba, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
+int tsp_colormap_rgb_host(tsp_context *ctx, const float *img, int H, int W, int C, float vmin, float vmax, float gamma,
+                          uint8_t *out_rgba8, float *out_rgba_f32) {
+    TSP_REQUIRE(ctx && img && (out_rgba8 || out_rgba_f32), TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(H > 0 && W > 0 && C >= 3, TSP_EINVAL, "bad image shape %dx%dx%d", H, W, C);
+    TSP_HIP(hipSetDevice(ctx->device));
+    const int64_t npix = (int64_t)H * W;
+    const size_t in_bytes = ((size_t)npix * C * sizeof(float) + 255) & ~(size_t)255;
+    const size_t o8 = ((size_t)npix * 4 + 255) & ~(size_t)255, of = (size_t)npix * 16;
+    int rc = ensure_scratch(ctx, in_bytes + o8 + of);
+    if (rc) return rc;
+    float *d_in = (float *)ctx->scratch;
+    uint8_t *d_o8 = (uint8_t *)ctx->scratch + in_bytes;
+    float *d_of = (float *)((uint8_t *)ctx->scratch + in_bytes + o8);
+    TSP_HIP(hipMemcpyAsync(d_in, img, (size_t)npix * C * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_colormap_rgb(ctx, d_in, npix, C, vmin, vmax, gamma, out_rgba8 ? d_o8 : nullptr,
+                                  out_rgba_f32 ? d_of : nullptr)))
+        return rc;
+    if (out_rgba8) TSP_HIP(hipMemcpyAsync(out_rgba8, d_o8, (size_t)npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_rgba_f32) TSP_HIP(hipMemcpyAsync(out_rgba_f32, d_of, of, hipMemcpyDeviceToHost, ctx->stream));
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
+int tsp_get_stats(tsp_context *ctx, tsp_stats *out) {
+    TSP_REQUIRE(ctx && out, TSP_EINVAL, "NULL argument");
+    *out = ctx->stats;
+    return TSP_OK;
+}
+
+int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
+    TSP_REQUIRE(ctx && name, TSP_EINVAL, "NULL argument");
+    if (!strcmp(name, "count_fragments")) {
+        ctx->count_fragments = value != 0;
+        return TSP_OK;
+    }
+    if (!strcmp(name, "use_quantity")) {      // 0: render density-only without dropping the resident q array
+        ctx->use_quantity = value != 0;
+        return TSP_OK;
+    }
+    if (!strcmp(name, "active_channels")) {   // layout tsp_write_image / the colormap calls assume
+        TSP_REQUIRE((value == 2 || value == 4) && value <= ctx->Ccap, TSP_EINVAL, "bad channel count %lld", (long long)value);
+        ctx->C = (int)value;
+        return TSP_OK;
+    }
+    set_error("unknown option '%s'", name);
+    return TSP_EINVAL;
+}
+
+int tsp_measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, double *gbps_out) {
+    TSP_REQUIRE(ctx && gbps_out && bytes > 0 && iters > 0, TSP_EINVAL, "bad argument");
+    TSP_HIP(hipSetDevice(ctx->device));
+    return measure_read_bandwidth(ctx, bytes, iters, gbps_out);
+}
+
+}  // extern "C"

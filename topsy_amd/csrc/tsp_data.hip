@@ -1,0 +1,298 @@
+// tsp_data.hip -- load-time data services (none of this runs per frame):
+//   * on-device synthetic snapshot with the distribution of topsy.loader.TestDataLoader
+//     (reference src/topsy/loader.py:241-332) from a counter-based generator;
+//   * load-time spatial ordering (stratified Morton), the analogue of the reference's cell sort
+//     at load (src/topsy/loader.py:88-97, src/topsy/cell_layout.py:63-113);
+//   * the float4 read-sum microbenchmark that measures the HBM streaming-read peak.
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+#include "tsp_internal.h"
+
+namespace tsp {
+
+// ------------------------------------------------------------------------------------------------
+// synthetic snapshot
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ double u01(uint64_t r) {  // (0, 1]
+    return ((double)(r >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+}
+
+struct SynthParams {
+    int64_t n_total, first, count;
+    uint64_t seed, mul, add;    // index bijection j = (mul * i + add) mod n_total
+    int64_t c0, c1;             // component boundaries: [0,c0) comp 0, [c0,c0+c1) comp 1, rest comp 2
+    float h_cap;
+};
+
+__global__ __launch_bounds__(256) void synth_kernel(SynthParams sp, float *x, float *y, float *z, float *h, float *m,
+                                                    float *q, float *r, float *g, float *b) {
+    // TestDataLoader: weights (0.5, 0.4, 0.1), means, stds (loader.py:245-247)
+    const double W[3] = {0.5, 0.4, 0.1};
+    const double MU[3][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {6.0, 10.0, 0.0}};
+    const double SD[3][3] = {{20.0, 20.0, 20.0}, {4.0, 0.2, 4.0}, {2.0, 2.0, 3.0}};
+    const double TWO_PI = 6.283185307179586;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < sp.count; t += (int64_t)gridDim.x * 256) {
+        const uint64_t i = (uint64_t)(sp.first + t);
+        const uint64_t j = (uint64_t)(((unsigned __int128)sp.mul * i + sp.add) % (uint64_t)sp.n_total);
+        const int comp = (int64_t)j < sp.c0 ? 0 : ((int64_t)j < sp.c0 + sp.c1 ? 1 : 2);
+        // 3 standard normals from 4 uniforms (Box-Muller), keyed by (seed, j)
+        const uint64_t k0 = splitmix64(sp.seed ^ (j * 4 + 0)), k1 = splitmix64(sp.seed ^ (j * 4 + 1));
+        const uint64_t k2 = splitmix64(sp.seed ^ (j * 4 + 2)), k3 = splitmix64(sp.seed ^ (j * 4 + 3));
+        const double r0 = sqrt(-2.0 * log(u01(k0))), r1 = sqrt(-2.0 * log(u01(k2)));
+        const double a0 = TWO_PI * u01(k1), a1 = TWO_PI * u01(k3);
+        const double n0 = r0 * cos(a0), n1 = r0 * sin(a0), n2 = r1 * cos(a1);
+        // pos = normal.astype(f32) * std + mean, stored as float32 (loader.py:283-287)
+        const float px = (float)((double)(float)n0 * SD[comp][0] + MU[comp][0]);
+        const float py = (float)((double)(float)n1 * SD[comp][1] + MU[comp][1]);
+        const float pz = (float)((double)(float)n2 * SD[comp][2] + MU[comp][2]);
+        // density (loader.py:265-272; note: no 1/2 in the exponent), h = 2 / den^0.333333 (:294-296)
+        double den = 0.0;
+        for (int c = 0; c < 3; ++c) {
+            const double dx = (double)px - MU[c][0], dy = (double)py - MU[c][1], dz = (double)pz - MU[c][2];
+            const double e = dx * dx / (SD[c][0] * SD[c][0]) + dy * dy / (SD[c][1] * SD[c][1]) +
+                             dz * dz / (SD[c][2] * SD[c][2]);
+            den += W[c] * exp(-e) / (15.749609945722419 /* (2 pi)^1.5 */ * SD[c][0] * SD[c][1] * SD[c][2]);
+        }
+        den *= (double)sp.n_total;
+        float hh = (float)(2.0 / pow(den, 0.333333));
+        if (sp.h_cap > 0.0f && !(hh < sp.h_cap)) hh = sp.h_cap;
+        x[t] = px; y[t] = py; z[t] = pz; h[t] = hh;
+        m[t] = 1e-8f;                                                    // loader.py:298-299
+        if (q) q[t] = sinf(px) * cosf(py) * cosf(pz) * 1e-4f;            // loader.py:301-303
+        if (r) {                                                         // loader.py:327-332
+            r[t] = fabsf(sinf(px / 10.0f));
+            g[t] = fabsf(cosf(py / 10.0f));
+            b[t] = fabsf(cosf(pz / 10.0f));
+        }
+    }
+}
+
+static uint64_t gcd64(uint64_t a, uint64_t b) {
+    while (b) { uint64_t t = a % b; a = b; b = t; }
+    return a;
+}
+
+int generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int64_t count, uint64_t seed, float h_cap,
+                       int with_quantity, int with_rgb) {
+    Particles &p = ctx->p;
+    p.n = count;
+    if (count == 0) return TSP_OK;
+    float **need[] = {&p.x, &p.y, &p.z, &p.h, &p.m};
+    for (float **a : need) TSP_HIP(hipMalloc((void **)a, (size_t)count * sizeof(float)));
+    if (with_quantity) TSP_HIP(hipMalloc((void **)&p.q, (size_t)count * sizeof(float)));
+    if (with_rgb) {
+        TSP_HIP(hipMalloc((void **)&p.r, (size_t)count * sizeof(float)));
+        TSP_HIP(hipMalloc((void **)&p.g, (size_t)count * sizeof(float)));
+        TSP_HIP(hipMalloc((void **)&p.b, (size_t)count * sizeof(float)));
+    }
+    SynthParams sp;
+    sp.n_total = n_total; sp.first = first; sp.count = count; sp.seed = seed; sp.h_cap = h_cap;
+    sp.c0 = (int64_t)((double)n_total * 0.5);   // int(N * w), loader.py:281
+    sp.c1 = (int64_t)((double)n_total * 0.4);
+    uint64_t mul = 1;
+    if (n_total > 2) {
+        mul = ((uint64_t)((double)n_total * 0.6180339887498949)) | 1ull;
+        while (gcd64(mul, (uint64_t)n_total) != 1) mul += 2;
+        mul %= (uint64_t)n_total;
+        if (mul == 0) mul = 1;
+    }
+    sp.mul = mul;
+    sp.add = splitmix64(seed) % (uint64_t)n_total;
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(synth_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, sp, p.x, p.y, p.z, p.h, p.m, p.q,
+                       p.r, p.g, p.b);
+    TSP_HIP(hipGetLastError());
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// load-time spatial ordering: key = (stratum << 48) | morton48(x, y, z)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ordered_u32(float f) {   // monotone float -> uint map
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float unordered_f32(unsigned u) {
+    const unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+
+__global__ void bbox_kernel(const float *x, const float *y, const float *z, int64_t n, unsigned *mm /*6*/) {
+    unsigned lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v[3] = {x[i], y[i], z[i]};
+        for (int k = 0; k < 3; ++k) {
+            if (v[k] != v[k] || __builtin_fabsf(v[k]) == __builtin_inff()) continue;
+            const unsigned o = ordered_u32(v[k]);
+            lo[k] = min(lo[k], o);
+            hi[k] = max(hi[k], o);
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        for (int off = 32; off; off >>= 1) {
+            lo[k] = min(lo[k], (unsigned)__shfl_xor((int)lo[k], off));
+            hi[k] = max(hi[k], (unsigned)__shfl_xor((int)hi[k], off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&mm[k], lo[k]);
+            atomicMax(&mm[3 + k], hi[k]);
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t part1by2(uint64_t x) {   // classic 21-bit spreader, used for 16 bits
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void morton_key_kernel(const float *x, const float *y, const float *z, int64_t n, float3 lo, float3 inv,
+                                  int n_strata, uint64_t seed, uint64_t *keys, uint32_t *vals) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float fx = (x[i] - lo.x) * inv.x, fy = (y[i] - lo.y) * inv.y, fz = (z[i] - lo.z) * inv.z;
+        fx = fx != fx ? 0.f : fminf(fmaxf(fx, 0.f), 65535.f);
+        fy = fy != fy ? 0.f : fminf(fmaxf(fy, 0.f), 65535.f);
+        fz = fz != fz ? 0.f : fminf(fmaxf(fz, 0.f), 65535.f);
+        const uint64_t mk = part1by2((uint64_t)fx) | (part1by2((uint64_t)fy) << 1) | (part1by2((uint64_t)fz) << 2);
+        const uint64_t stratum = n_strata > 1 ? splitmix64(seed ^ (uint64_t)i) % (uint64_t)n_strata : 0;
+        keys[i] = (stratum << 48) | mk;
+        vals[i] = (uint32_t)i;
+    }
+}
+
+__global__ void gather_f32_kernel(const float *__restrict__ src, const uint32_t *__restrict__ idx,
+                                  float *__restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[idx[i]];
+}
+__global__ void gather_u32_kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx,
+                                  uint32_t *__restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[idx[i]];
+}
+
+int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out) {
+    Particles &p = ctx->p;
+    const int64_t n = p.n;
+    hipStream_t st = ctx->stream;
+    unsigned *mm = nullptr;
+    TSP_HIP(hipMalloc((void **)&mm, 6 * sizeof(unsigned)));
+    const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0};
+    TSP_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(bbox_kernel, dim3(1024), dim3(256), 0, st, p.x, p.y, p.z, n, mm);
+    unsigned hmm[6];
+    TSP_HIP(hipMemcpyAsync(hmm, mm, sizeof(hmm), hipMemcpyDeviceToHost, st));
+    TSP_HIP(hipStreamSynchronize(st));
+    TSP_HIP(hipFree(mm));
+    float lo[3], inv[3];
+    for (int k = 0; k < 3; ++k) {
+        const float a = unordered_f32(hmm[k]), b = unordered_f32(hmm[3 + k]);
+        lo[k] = a;
+        inv[k] = (b > a) ? 65535.0f / (b - a) : 0.0f;
+    }
+    uint64_t *keys = nullptr, *keys2 = nullptr;
+    uint32_t *vals = nullptr, *vals2 = nullptr;
+    TSP_HIP(hipMalloc((void **)&keys, (size_t)n * 8));
+    TSP_HIP(hipMalloc((void **)&keys2, (size_t)n * 8));
+    TSP_HIP(hipMalloc((void **)&vals, (size_t)n * 4));
+    TSP_HIP(hipMalloc((void **)&vals2, (size_t)n * 4));
+    hipLaunchKernelGGL(morton_key_kernel, dim3(4096), dim3(256), 0, st, p.x, p.y, p.z, n,
+                       make_float3(lo[0], lo[1], lo[2]), make_float3(inv[0], inv[1], inv[2]), n_strata, seed, keys, vals);
+    TSP_HIP(hipGetLastError());
+    size_t tmp_bytes = 0;
+    TSP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, n, 0, 60, st));
+    void *tmp = nullptr;
+    TSP_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    TSP_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, n, 0, 60, st));
+    TSP_HIP(hipStreamSynchronize(st));
+    TSP_HIP(hipFree(tmp));
+    TSP_HIP(hipFree(keys));
+    TSP_HIP(hipFree(keys2));
+    TSP_HIP(hipFree(vals));
+    // vals2[new] = old index (relative to the current order)
+    float *buf = nullptr;
+    TSP_HIP(hipMalloc((void **)&buf, (size_t)n * 4));
+    float **arrs[] = {&p.x, &p.y, &p.z, &p.h, &p.m, &p.q, &p.r, &p.g, &p.b};
+    for (float **a : arrs) {
+        if (!*a) continue;
+        hipLaunchKernelGGL(gather_f32_kernel, dim3(4096), dim3(256), 0, st, *a, vals2, buf, n);
+        TSP_HIP(hipGetLastError());
+        TSP_HIP(hipStreamSynchronize(st));
+        float *t = *a; *a = buf; buf = t;
+    }
+    if (p.perm) {   // compose with an earlier reordering: perm_new[i] = perm_old[vals2[i]]
+        hipLaunchKernelGGL(gather_u32_kernel, dim3(4096), dim3(256), 0, st, p.perm, vals2, (uint32_t *)buf, n);
+        TSP_HIP(hipGetLastError());
+        TSP_HIP(hipStreamSynchronize(st));
+        uint32_t *t = p.perm; p.perm = (uint32_t *)buf; buf = (float *)t;
+        TSP_HIP(hipFree(vals2));
+    } else {
+        p.perm = vals2;
+    }
+    TSP_HIP(hipFree(buf));
+    if (perm_out) {
+        std::vector<uint32_t> hp((size_t)n);
+        TSP_HIP(hipMemcpy(hp.data(), p.perm, (size_t)n * 4, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) perm_out[i] = (int64_t)hp[(size_t)i];
+    }
+    return TSP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HBM streaming-read microbenchmark: float4 read-sum
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void read_sum_kernel(const float4 *__restrict__ src, int64_t n4, float *sink) {
+    float acc = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
+    }
+    for (; i < n4; i += stride) {
+        const float4 a = src[i];
+        acc += a.x + a.y + a.z + a.w;
+    }
+    if (acc == 123.456f) *sink = acc;   // keep the loads alive
+}
+
+int measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, double *gbps_out) {
+    bytes &= ~(int64_t)4095;
+    if (bytes < 4096) bytes = 4096;
+    float4 *buf = nullptr;
+    float *sink = nullptr;
+    TSP_HIP(hipMalloc((void **)&buf, (size_t)bytes));
+    TSP_HIP(hipMalloc((void **)&sink, 4));
+    TSP_HIP(hipMemsetAsync(buf, 0x11, (size_t)bytes, ctx->stream));
+    const unsigned grid = (unsigned)ctx->cu_count * 8;
+    hipLaunchKernelGGL(read_sum_kernel, dim3(grid), dim3(256), 0, ctx->stream, buf, bytes / 16, sink);
+    TSP_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    for (int it = 0; it < iters; ++it)
+        hipLaunchKernelGGL(read_sum_kernel, dim3(grid), dim3(256), 0, ctx->stream, buf, bytes / 16, sink);
+    TSP_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+    *gbps_out = (double)bytes * iters / (ms * 1e-3) / 1e9;
+    TSP_HIP(hipFree(buf));
+    TSP_HIP(hipFree(sink));
+    return TSP_OK;
+}
+
+}  // namespace tsp

@@ -1,0 +1,109 @@
+// tsp_internal.h -- context layout and helpers shared by the translation units of libtopsy_splat.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/topsy_splat.h"
+#include "tsp_math.h"
+
+namespace tsp {
+
+void set_error(const char *fmt, ...);
+
+#define TSP_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            tsp::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return TSP_EHIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+#define TSP_REQUIRE(cond, code, ...)       \
+    do {                                   \
+        if (!(cond)) {                     \
+            tsp::set_error(__VA_ARGS__);   \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+// Resident particle data: struct-of-arrays float32 in HBM, one allocation per attribute so each
+// streams as an independent fully-coalesced sequence (20 B/particle density, 24 B with q, 28 B rgb).
+struct Particles {
+    int64_t n = 0;
+    float *x = nullptr, *y = nullptr, *z = nullptr, *h = nullptr, *m = nullptr;
+    float *q = nullptr;                      // nullptr -> density render (q = 0)
+    float *r = nullptr, *g = nullptr, *b = nullptr;
+    uint32_t *perm = nullptr;                // new -> old index after tsp_reorder_spatial (else nullptr)
+};
+
+// Deferred-footprint record written by the streaming kernel for the tile kernels (20 B).
+struct Record {
+    float pcx, pcy, P, w0, w1;
+};
+struct Record4 {   // rgb variant (24 B)
+    float pcx, pcy, P, w0, w1, w2;
+};
+
+struct Counters {      // device-side, zeroed per render call
+    unsigned long long n_small, n_mid, n_huge, n_culled, n_fragments, huge_count, pad0, pad1;
+};
+
+struct Workspace {     // per-context scratch for the three-class pipeline (grown on demand)
+    void *mid_records = nullptr;      // capacity: one slot per visited particle
+    int64_t mid_capacity = 0;
+    void *huge_records = nullptr;
+    int64_t huge_capacity = 0;
+    int *seg_count = nullptr;         // per chunk: number of mid records
+    float4 *seg_bbox = nullptr;       // per chunk: pixel bbox of its mid records (x0,y0,x1,y1)
+    int64_t seg_capacity = 0;
+    int64_t *range_prefix = nullptr;  // device copy of ranges (starts, lens, chunk prefix)
+    int64_t range_capacity = 0;
+};
+
+}  // namespace tsp
+
+struct tsp_context {
+    int device = 0;
+    int R = 0, C = 0, Ccap = 0;       // C = active channels (2 or 4) <= Ccap
+    bool use_quantity = true;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    float *image = nullptr;           // R*R*C float32 render target
+    float *mips = nullptr;            // 5440 floats
+    bool have_mips = false;
+    tsp::Particles p;
+    tsp::Counters *counters = nullptr;
+    tsp::Workspace ws;
+    uint8_t *out8 = nullptr;          // R*R*4 staging for colormap output
+    float *outf = nullptr;            // R*R*4 float staging (HDR)
+    float *lut = nullptr;             // colormap LUT on device
+    int lut_capacity = 0;
+    void *scratch = nullptr;          // host-image colormap staging
+    size_t scratch_bytes = 0;
+    tsp_stats stats = {};
+    bool count_fragments = false;
+    int cu_count = 256;
+    // RCCL
+    void *comm = nullptr;
+    int n_ranks = 1, rank = 0;
+};
+
+namespace tsp {
+// kernels / launchers implemented in the other translation units
+int launch_generic(tsp_context *ctx, const Camera &cam, const int64_t *d_ranges, int n_ranges,
+                   int64_t total, int mode);
+int launch_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_starts, const int64_t *h_lens,
+                    int n_ranges, int64_t total, int mode);
+int launch_colormap_scalar(tsp_context *ctx, const float *d_img, int64_t npix, int C, const float *d_lut,
+                           int n_lut, float vmin, float vmax, int log_scale, int weighted, uint8_t *d_out);
+int launch_colormap_rgb(tsp_context *ctx, const float *d_img, int64_t npix, int C, float vmin, float vmax,
+                        float gamma, uint8_t *d_out8, float *d_outf);
+int generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int64_t count, uint64_t seed,
+                       float h_cap, int with_quantity, int with_rgb);
+int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out);
+int measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, double *gbps_out);
+int ensure_array(float **p, int64_t n);
+}  // namespace tsp
