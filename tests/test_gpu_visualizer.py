@@ -135,6 +135,10 @@ def test_progressive_frames_fold_mass_scale():
     full = v._sph.get_image().copy()
     rp = v._sph._render_progression
     rp._recommended_num_particles_to_render = 50000
+    # pretend every block costs 40 ms of GPU time, so the 1/30 s budget admits one block per frame
+    timer = v._sph._render_timer
+    real_add = timer.add_block
+    timer.add_block = lambda ms: real_add(40.0)
     v.invalidate()
     v.draw(DrawReason.CHANGE)
     assert v._sph.last_render_mass_scale == pytest.approx(4.0, rel=1e-3)

@@ -1,5 +1,6 @@
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 from conftest import make_cloud
 from oracle import oracle_np, oracle_c
@@ -9,25 +10,23 @@ pos, h, m, q, _ = make_cloud(20000, seed=3)
 M, sf = oracle_np.transform_matrix(np.eye(3), np.zeros(3), 200.0)
 x, y, z = (np.ascontiguousarray(pos[:, k]) for k in range(3))
 R = 1024
-want, nf = oracle_c.splat(x, y, z, h, m, q, mode=0, M=M, sf=sf, R=R, mips=mips)
 ctx = _native.Context(R, 2); ctx.set_kernel_mips(mips)
-ctx.upload_particles(x, y, z, h, m); ctx.upload_quantity(q)
 ctx.set_option("count_fragments", 1)
-ms = ctx.render(M, sf, flags=_native.PIPE_GENERIC)
-got = ctx.read_image()
-print("ms", ms, ctx.stats(), "oracle frags", nf)
-d = np.abs(got[..., 0] - want[..., 0]); rel = d / np.maximum(np.abs(want[..., 0]), 1e-30)
-bad = rel > 1e-5
-print("bad px", bad.sum(), "max rel", rel.max(), "nan got", np.isnan(got).sum())
-jj, ii = np.where(bad)
-for j, i in list(zip(jj, ii))[:10]:
-    print(j, i, got[j, i, 0], want[j, i, 0])
-# try single particles to isolate
-for lo, hi in [(0.02, 1), (1, 8), (8, 64), (64, 1000)]:
-    P = 2 * h * R / 200.0
-    sel = (P >= lo) & (P < hi)
-    w2, _ = oracle_c.splat(x[sel], y[sel], z[sel], h[sel], m[sel], q[sel], mode=0, M=M, sf=sf, R=R, mips=mips)
+def cmp(sel, label, flags=_native.PIPE_DEFAULT):
+    w2, nf = oracle_c.splat(x[sel], y[sel], z[sel], h[sel], m[sel], q[sel], mode=0, M=M, sf=sf, R=R, mips=mips)
     ctx.upload_particles(x[sel], y[sel], z[sel], h[sel], m[sel]); ctx.upload_quantity(q[sel])
-    ctx.render(M, sf, flags=_native.PIPE_GENERIC); g2 = ctx.read_image()
-    rel = np.abs(g2[..., 0] - w2[..., 0]) / np.maximum(np.abs(w2[..., 0]), 1e-30)
-    print("class", lo, hi, sel.sum(), "max rel", rel.max(), "bad", (rel > 1e-5).sum(), "frags", ctx.stats()['n_fragments'])
+    ms = ctx.render(M, sf, flags=flags); g2 = ctx.read_image()
+    rel = np.abs(g2[..., 0] - w2[..., 0]) / np.maximum(np.abs(w2[..., 0]).astype(np.float64), 1e-300)
+    rel[(w2[..., 0] == 0) & (g2[..., 0] == 0)] = 0
+    st = ctx.stats()
+    print(f"{label}: n={sel.sum()} max rel {rel.max():.3g} bad {(rel > 1e-5).sum()} frags gpu {st['n_fragments']} oracle {nf} "
+          f"small/mid/huge/cull {st['n_small']}/{st['n_mid']}/{st['n_huge']}/{st['n_culled']} ms {ms:.3f} (S {st['ms_stream']:.3f} M {st['ms_mid']:.3f} H {st['ms_huge']:.3f})")
+    return g2, w2, rel
+P = 2 * h * R / 200.0
+allsel = np.ones(len(h), bool)
+g, w, rel = cmp(allsel, "all")
+jj, ii = np.where(rel > 1e-5)
+for j, i in list(zip(jj, ii))[:8]:
+    print("   px", j, i, g[j, i, 0], w[j, i, 0], rel[j, i])
+for lo, hi in [(0, 4), (4, 64), (64, 1e9)]:
+    cmp((P >= lo) & (P < hi), f"class P in [{lo},{hi})")

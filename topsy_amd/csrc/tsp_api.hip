@@ -127,7 +127,8 @@ void tsp_destroy(tsp_context *ctx) {
     tsp_comm_destroy(ctx);
     free_particles(ctx);
     void *ptrs[] = {ctx->image, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->scratch,
-                    ctx->ws.mid_records, ctx->ws.huge_records, ctx->ws.seg_count, ctx->ws.seg_bbox, ctx->ws.range_prefix};
+                    ctx->ws.mid_geom, ctx->ws.mid_w, ctx->ws.huge_geom, ctx->ws.huge_w, ctx->ws.seg_count, ctx->ws.seg_offset,
+                    ctx->ws.seg_bbox, ctx->ws.range_prefix};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &e : ctx->ev)
@@ -440,6 +441,18 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
     TSP_REQUIRE(ctx && name, TSP_EINVAL, "NULL argument");
     if (!strcmp(name, "count_fragments")) {
         ctx->count_fragments = value != 0;
+        return TSP_OK;
+    }
+    if (!strcmp(name, "p_small_milli")) {     // class boundary small/mid in 1/1000 px (<= 11313: small is always mip 3)
+        TSP_REQUIRE(value >= 0 && value <= 11313, TSP_EINVAL, "p_small out of range");
+        ctx->p_small = (float)value * 1e-3f;
+        return TSP_OK;
+    }
+    if (!strcmp(name, "mid_split") || !strcmp(name, "huge_split") || !strcmp(name, "stream_blocks_per_cu")) {
+        TSP_REQUIRE(value >= 0 && value <= 64, TSP_EINVAL, "%s out of range", name);
+        if (name[0] == 'm') ctx->mid_split = value > 0 ? (int)value : 1;
+        else if (name[0] == 'h') ctx->huge_split = (int)value;
+        else ctx->stream_blocks_per_cu = value > 0 ? (int)value : 1;
         return TSP_OK;
     }
     if (!strcmp(name, "use_quantity")) {      // 0: render density-only without dropping the resident q array

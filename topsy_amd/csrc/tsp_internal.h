@@ -51,15 +51,16 @@ struct Counters {      // device-side, zeroed per render call
     unsigned long long n_small, n_mid, n_huge, n_culled, n_fragments, huge_count, pad0, pad1;
 };
 
-struct Workspace {     // per-context scratch for the three-class pipeline (grown on demand)
-    void *mid_records = nullptr;      // capacity: one slot per visited particle
+struct Workspace {     // per-context scratch of the three-class pipeline (grown on demand)
+    void *mid_geom = nullptr, *mid_w = nullptr;     // deferred mid footprints: float4 geometry + weights
     int64_t mid_capacity = 0;
-    void *huge_records = nullptr;
+    void *huge_geom = nullptr, *huge_w = nullptr;   // deferred huge footprints
     int64_t huge_capacity = 0;
-    int *seg_count = nullptr;         // per chunk: number of mid records
-    float4 *seg_bbox = nullptr;       // per chunk: pixel bbox of its mid records (x0,y0,x1,y1)
+    int *seg_count = nullptr;           // per chunk: number of mid records
+    long long *seg_offset = nullptr;    // per chunk: first record of its contiguous run
+    float4 *seg_bbox = nullptr;         // per chunk: pixel bbox of its mid footprints (x0, y0, x1, y1)
     int64_t seg_capacity = 0;
-    int64_t *range_prefix = nullptr;  // device copy of ranges (starts, lens, chunk prefix)
+    int64_t *range_prefix = nullptr;    // device copy of the ranges of the current call
     int64_t range_capacity = 0;
 };
 
@@ -85,6 +86,10 @@ struct tsp_context {
     size_t scratch_bytes = 0;
     tsp_stats stats = {};
     bool count_fragments = false;
+    // pipeline tuning (tsp_set_option)
+    float p_small = 4.0f;             // footprints narrower than this many pixels are splatted by kernel S
+    int mid_split = 16, huge_split = 0;  // workgroups per image tile (0 = auto)
+    int stream_blocks_per_cu = 4;
     int cu_count = 256;
     // RCCL
     void *comm = nullptr;

@@ -1,32 +1,832 @@
-// tsp_pipeline.hip -- the three-class splat pipeline (default render path).
+// tsp_pipeline.hip -- the three-class splat pipeline (default render path), gfx950.
+//
+// What it computes is exactly vertex_* + fragment_* + additive blend of the reference
+// (src/topsy/shaders/sph.wgsl:54-91,139-165; src/topsy/sph.py:31-42) in the canonical arithmetic of
+// tsp_math.h.  How it is scheduled is MI355X-specific and driven by the footprint distribution
+// (DESIGN.md section 4): 80 % of particles cover < 8 px but > 90 % of all pixel updates come from the
+// ~1 % of particles wider than 64 px.
+//
+//   kernel S  splat_stream_kernel  streams the SoA particle arrays once (coalesced, 2048-particle
+//             chunks per workgroup, consecutive chunks per workgroup so load-time spatial order gives
+//             screen locality).  Footprints < p_small px are rasterised at once into a 64x64-pixel
+//             LDS window that follows the chunks (ds_add_f32), flushed with one global atomic per
+//             touched pixel.  Wider footprints are not rasterised here: their projected records
+//             (pcx, pcy, P, weights) are appended to the MID list (per-chunk contiguous segments with
+//             a pixel bounding box) or the HUGE list.
+//   kernel M  splat_mid_kernel     one workgroup per (64x64 image tile, split): walks the segments
+//             whose bbox meets the tile; each wave rasterises its records' footprints restricted to
+//             the tile, 8x8 lanes per step, nearest-mip sampling from an LDS copy of the mip pyramid,
+//             ds_add_f32 into the LDS tile (row stride 72: conflict-free for 8x8 lane blocks).
+//   kernel H  splat_huge_kernel    one workgroup per (64x64 tile, split): every lane owns a 4x4 pixel
+//             block in registers (no atomics in the loop); records overlapping the tile are compacted
+//             into an LDS queue and evaluated by all 256 lanes with bilinear sampling from an LDS
+//             "quad table" (one ds_read_b128 fetches the 2x2 texel stencil of a pixel).
+//
+// All three add into the float32 render target with device-scope atomics only at flush time.
+#include <string.h>
+
+#include <algorithm>
 #include <vector>
 
 #include "tsp_internal.h"
 
 namespace tsp {
 
-int launch_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_starts, const int64_t *h_lens, int n_ranges,
-                    int64_t total, int mode) {
-    // interim: route through the generic kernel until the class kernels land
+constexpr int CHUNK = 2048;          // particles per chunk
+constexpr int KPT = CHUNK / 256;     // particles per thread per chunk
+constexpr int TILE = 64;             // image tile edge of kernel H (and tile width of kernel M)
+constexpr int MTILE_H = 32;          // tile height of kernel M (64 x 32 pixels per workgroup)
+constexpr int MSTR = 72;             // LDS row stride (doubles) of the mid tile
+// LDS accumulators are DOUBLE: on gfx950 ds_add_f64 costs ~20 clk per wave-instruction while
+// ds_add_f32 costs ~190 (measured, tools/ubench/lds_atomics.hip), and the sums gain precision.
+template <int MODE> struct WinSize { static constexpr int value = (MODE == TSP_MODE_RGB) ? 48 : 64; };
+
+enum { CLS_NONE = 0, CLS_SMALL = 1, CLS_MID = 2, CLS_HUGE = 3 };
+
+__device__ __forceinline__ void gatomic_add(float *addr, float v) {
+    __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void latomic_add(double *addr, float v) {
+    __hip_atomic_fetch_add(addr, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-wide helpers (256 threads = 4 waves)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_min(float v) {
+    for (int o = 32; o; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+struct StreamArgs {
+    Particles p;
+    const int64_t *ranges;     // starts[n] | lens[n] | chunk_prefix[n+1]
+    int n_ranges;
+    int n_chunks;
+    int chunks_per_block;
+    Camera cam;
+    const float *mips;
+    float *img;
+    float4 *mid_geom;  float *mid_w;   int64_t mid_capacity;
+    float4 *huge_geom; float *huge_w;  int64_t huge_capacity;
+    int *seg_count; long long *seg_offset; float4 *seg_bbox;
+    Counters *cnt;
+    float p_small;
+    int count_frag;
+    int emit_small;            // 0: records only (replay after a record-list overflow)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void splat_stream_kernel(StreamArgs a) {
+    constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
+    constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;      // extra weights per record
+    constexpr int WIN = WinSize<MODE>::value;
+    extern __shared__ __attribute__((aligned(16))) double smem_d[];
+    double *win = smem_d;                                            // [C][WIN*WIN]
+    float *T3 = reinterpret_cast<float *>(win + C * WIN * WIN);      // mip level 3: 8x8
+    __shared__ float s_red[4][4];
+    __shared__ int s_cnt[4][2];
+    __shared__ long long s_base[2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const Camera &cam = a.cam;
+    const int R = cam.R;
+    for (int i = tid; i < C * WIN * WIN; i += 256) win[i] = 0.0;
+    if (tid < 64) T3[tid] = a.mips[5376 + tid];
+    __syncthreads();
+
+    // window state (uniform): origin and the dirty rectangle (window coordinates, inclusive)
+    int wox = 0, woy = 0;
+    int dx0 = WIN, dy0 = WIN, dx1 = -1, dy1 = -1;
+    unsigned long long n_small = 0, n_cull = 0, n_frag = 0;
+
+    const int c_begin = blockIdx.x * a.chunks_per_block;
+    const int c_end = min(c_begin + a.chunks_per_block, a.n_chunks);
+    const int64_t *starts = a.ranges, *lens = a.ranges + a.n_ranges, *cprefix = a.ranges + 2 * a.n_ranges;
+
+    auto flush = [&]() {
+        // one global atomic per touched pixel and channel; only the dirty rectangle is visited
+        if (dx1 >= dx0) {
+            const int fw = dx1 - dx0 + 1, fn = fw * (dy1 - dy0 + 1);
+            for (int idx = tid; idx < fn; idx += 256) {
+                const int jj = idx / fw;
+                const int wy = dy0 + jj, wx = dx0 + (idx - jj * fw);
+                const int gx = wox + wx, gy = woy + wy;
+                const int o = wy * WIN + wx;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const double v = win[c * WIN * WIN + o];
+                    if (v != 0.0) {
+                        if (gx < R && gy < R) gatomic_add(a.img + ((size_t)gy * R + gx) * C + c, (float)v);
+                        win[c * WIN * WIN + o] = 0.0;
+                    }
+                }
+            }
+        }
+        dx0 = WIN; dy0 = WIN; dx1 = -1; dy1 = -1;
+    };
+
+    for (int c = c_begin; c < c_end; ++c) {
+        // ---- locate the chunk: range r, particles [first, first + cnt) -------------------------
+        int r = 0;
+        if (a.n_ranges > 1) {
+            int lo = 0, hi = a.n_ranges - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (cprefix[mid] <= c) lo = mid; else hi = mid - 1;
+            }
+            r = lo;
+        }
+        const int64_t in_range = (int64_t)(c - cprefix[r]) * CHUNK;
+        const int64_t first = starts[r] + in_range;
+        const int cnt = (int)min((int64_t)CHUNK, lens[r] - in_range);
+
+        // ---- phase 1: coalesced loads, projection, classification ------------------------------
+        float pcx[KPT], pcy[KPT], PP[KPT], w0[KPT], w1[KPT], w2[KPT];
+        int cls[KPT];
+        float bx0 = 3.0e38f, by0 = 3.0e38f, bx1 = -3.0e38f, by1 = -3.0e38f;      // small footprints
+        float mx0 = 3.0e38f, my0 = 3.0e38f, mx1 = -3.0e38f, my1 = -3.0e38f;      // mid footprints
+        int my_mid = 0, my_huge = 0;
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int li = k * 256 + tid;
+            cls[k] = CLS_NONE;
+            pcx[k] = pcy[k] = PP[k] = w0[k] = w1[k] = w2[k] = 0.0f;
+            if (li < cnt) {
+                const int64_t i = first + li;
+                const float h = a.p.h[i];
+                const Proj pr = project(cam, a.p.x[i], a.p.y[i], a.p.z[i], h);
+                bool vis = false;
+                if (pr.keep) {
+                    // any pixel centre covered?  (exact test via the canonical interval)
+                    int ilo, ihi, jlo, jhi;
+                    cover_range(pr.pcx, pr.half, R, ilo, ihi);
+                    cover_range(pr.pcy, pr.half, R, jlo, jhi);
+                    vis = (ilo <= ihi) && (jlo <= jhi);
+                }
+                if (vis) {
+                    const float hh = h * h;
+                    if (MODE == TSP_MODE_RGB) {
+                        w0[k] = a.p.r[i] / hh; w1[k] = a.p.g[i] / hh; w2[k] = a.p.b[i] / hh;
+                    } else {
+                        w0[k] = a.p.m[i] / hh;
+                        w1[k] = (MODE == TSP_MODE_DEPTH) ? pr.cz : (a.p.q ? a.p.q[i] : 0.0f);
+                    }
+                    pcx[k] = pr.pcx; pcy[k] = pr.pcy; PP[k] = pr.P;
+                    if (pr.P < a.p_small) {
+                        cls[k] = CLS_SMALL;
+                        bx0 = fminf(bx0, pr.pcx - pr.half); bx1 = fmaxf(bx1, pr.pcx + pr.half);
+                        by0 = fminf(by0, pr.pcy - pr.half); by1 = fmaxf(by1, pr.pcy + pr.half);
+                    } else if (pr.P < P_BILINEAR) {
+                        cls[k] = CLS_MID; ++my_mid;
+                        mx0 = fminf(mx0, pr.pcx - pr.half); mx1 = fmaxf(mx1, pr.pcx + pr.half);
+                        my0 = fminf(my0, pr.pcy - pr.half); my1 = fmaxf(my1, pr.pcy + pr.half);
+                    } else {
+                        cls[k] = CLS_HUGE; ++my_huge;
+                    }
+                } else {
+                    ++n_cull;
+                }
+            }
+        }
+
+        // ---- phase 2: block reductions (small bbox, mid bbox, record counts + offsets) ---------
+        bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1);
+        const int mid_incl = wave_incl_scan(my_mid, lane), huge_incl = wave_incl_scan(my_huge, lane);
+        __syncthreads();       // previous chunk's readers of s_* are done
+        if (lane == 63) { s_cnt[wv][0] = mid_incl; s_cnt[wv][1] = huge_incl; }
+        if (lane == 0) { s_red[wv][0] = bx0; s_red[wv][1] = by0; s_red[wv][2] = bx1; s_red[wv][3] = by1; }
+        __syncthreads();
+        bx0 = fminf(fminf(s_red[0][0], s_red[1][0]), fminf(s_red[2][0], s_red[3][0]));
+        by0 = fminf(fminf(s_red[0][1], s_red[1][1]), fminf(s_red[2][1], s_red[3][1]));
+        bx1 = fmaxf(fmaxf(s_red[0][2], s_red[1][2]), fmaxf(s_red[2][2], s_red[3][2]));
+        by1 = fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3]));
+        int mid_before = 0, huge_before = 0, mid_total = 0, huge_total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wv) { mid_before += s_cnt[w][0]; huge_before += s_cnt[w][1]; }
+            mid_total += s_cnt[w][0]; huge_total += s_cnt[w][1];
+        }
+        // mid bbox (only needed when the chunk has mid records)
+        if (mid_total > 0) {
+            mx0 = wave_min(mx0); my0 = wave_min(my0); mx1 = wave_max(mx1); my1 = wave_max(my1);
+            __syncthreads();
+            if (lane == 0) { s_red[wv][0] = mx0; s_red[wv][1] = my0; s_red[wv][2] = mx1; s_red[wv][3] = my1; }
+            __syncthreads();
+            mx0 = fminf(fminf(s_red[0][0], s_red[1][0]), fminf(s_red[2][0], s_red[3][0]));
+            my0 = fminf(fminf(s_red[0][1], s_red[1][1]), fminf(s_red[2][1], s_red[3][1]));
+            mx1 = fmaxf(fmaxf(s_red[0][2], s_red[1][2]), fmaxf(s_red[2][2], s_red[3][2]));
+            my1 = fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3]));
+        }
+        // reserve contiguous runs in the record lists (one atomic per chunk and list)
+        if (tid == 0) {
+            s_base[0] = mid_total ? (long long)atomicAdd(&a.cnt->n_mid, (unsigned long long)mid_total) : 0;
+            s_base[1] = huge_total ? (long long)atomicAdd(&a.cnt->n_huge, (unsigned long long)huge_total) : 0;
+            a.seg_count[c] = mid_total;
+            a.seg_offset[c] = s_base[0];
+            if (mid_total) a.seg_bbox[c] = make_float4(mx0, my0, mx1, my1);
+        }
+        __syncthreads();
+        const long long mid_base = s_base[0], huge_base = s_base[1];
+
+        // ---- phase 3: window placement (uniform) -------------------------------------------------
+        if (bx1 >= bx0) {
+            const int ix0 = max((int)__builtin_floorf(bx0), 0), ix1 = min((int)__builtin_floorf(bx1), R - 1);
+            const int iy0 = max((int)__builtin_floorf(by0), 0), iy1 = min((int)__builtin_floorf(by1), R - 1);
+            const bool inside = ix0 >= wox && ix1 < wox + WIN && iy0 >= woy && iy1 < woy + WIN;
+            if (!inside) {
+                flush();
+                __syncthreads();
+                // centre the window on the chunk's small-footprint bounding box
+                wox = (ix0 + ix1 + 1 - WIN) / 2;
+                woy = (iy0 + iy1 + 1 - WIN) / 2;
+                wox = max(0, min(wox, R - WIN));
+                woy = max(0, min(woy, R - WIN));
+                wox = max(wox, 0); woy = max(woy, 0);
+            }
+            // dirty rectangle grows by this chunk's bbox (clipped to the window)
+            dx0 = min(dx0, max(ix0 - wox, 0)); dx1 = max(dx1, min(ix1 - wox, WIN - 1));
+            dy0 = min(dy0, max(iy0 - woy, 0)); dy1 = max(dy1, min(iy1 - woy, WIN - 1));
+        }
+
+        // ---- phase 4: rasterise small footprints (one lane per particle, mip 3 nearest) ---------
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            if (cls[k] != CLS_SMALL || !a.emit_small) continue;
+            const float half = 0.5f * PP[k], invP = 1.0f / PP[k];
+            int ilo, ihi, jlo, jhi;
+            cover_range(pcx[k], half, R, ilo, ihi);
+            cover_range(pcy[k], half, R, jlo, jhi);
+            for (int j = jlo; j <= jhi; ++j) {
+                const float dy = ((float)j + 0.5f) - pcy[k];
+                const int ty = nearest_index((dy + half) * invP, 8);
+                const int wy = j - woy;
+                for (int i = ilo; i <= ihi; ++i) {
+                    const float dx = ((float)i + 0.5f) - pcx[k];
+                    const int tx = nearest_index((dx + half) * invP, 8);
+                    const float kv = T3[ty * 8 + tx];
+                    const int wx = i - wox;
+                    const bool inw = (unsigned)wx < (unsigned)WIN && (unsigned)wy < (unsigned)WIN;
+                    if (MODE == TSP_MODE_RGB) {
+                        const float v0 = kv * w0[k], v1 = kv * w1[k], v2 = kv * w2[k];
+                        if (inw) {
+                            double *d = win + wy * WIN + wx;
+                            latomic_add(d, v0); latomic_add(d + WIN * WIN, v1);
+                            latomic_add(d + 2 * WIN * WIN, v2); latomic_add(d + 3 * WIN * WIN, 1.0f);
+                        } else {
+                            float *d = a.img + ((size_t)j * R + i) * C;
+                            gatomic_add(d, v0); gatomic_add(d + 1, v1); gatomic_add(d + 2, v2); gatomic_add(d + 3, 1.0f);
+                        }
+                    } else {
+                        const float val = kv * w0[k];
+                        const float v1 = val * w1[k];
+                        if (inw) {
+                            double *d = win + wy * WIN + wx;
+                            latomic_add(d, val); latomic_add(d + WIN * WIN, v1);
+                        } else {
+                            float *d = a.img + ((size_t)j * R + i) * C;
+                            gatomic_add(d, val); gatomic_add(d + 1, v1);
+                        }
+                    }
+                }
+            }
+            ++n_small;
+            if (a.count_frag) n_frag += (unsigned long long)((ihi - ilo + 1) * (jhi - jlo + 1));
+        }
+
+        // ---- phase 5: append the deferred footprints -----------------------------------------------
+        if (mid_total | huge_total) {
+            long long mpos = mid_base + mid_before + (mid_incl - my_mid);
+            long long hpos = huge_base + huge_before + (huge_incl - my_huge);
+#pragma unroll
+            for (int k = 0; k < KPT; ++k) {
+                if (cls[k] == CLS_MID) {
+                    if (mpos < a.mid_capacity) {
+                        a.mid_geom[mpos] = make_float4(pcx[k], pcy[k], PP[k], w0[k]);
+                        a.mid_w[mpos * NW] = w1[k];
+                        if (NW == 2) a.mid_w[mpos * NW + 1] = w2[k];
+                    }
+                    ++mpos;
+                } else if (cls[k] == CLS_HUGE) {
+                    if (hpos < a.huge_capacity) {
+                        a.huge_geom[hpos] = make_float4(pcx[k], pcy[k], PP[k], w0[k]);
+                        a.huge_w[hpos * NW] = w1[k];
+                        if (NW == 2) a.huge_w[hpos * NW + 1] = w2[k];
+                    }
+                    ++hpos;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    flush();
+    // statistics (one atomic per wave)
+    for (int o = 32; o; o >>= 1) {
+        n_small += __shfl_xor((long long)n_small, o);
+        n_cull += __shfl_xor((long long)n_cull, o);
+        n_frag += __shfl_xor((long long)n_frag, o);
+    }
+    if (lane == 0) {
+        if (n_small) atomicAdd(&a.cnt->n_small, n_small);
+        if (n_cull) atomicAdd(&a.cnt->n_culled, n_cull);
+        if (n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel M: mid footprints (p_small <= P < 64), tile scatter with nearest-mip sampling
+// ---------------------------------------------------------------------------------------------
+struct TileArgs {
+    const float4 *geom; const float *w;
+    long long n_records;
+    const int *seg_count; const long long *seg_offset; const float4 *seg_bbox; int n_chunks;
+    Camera cam;
+    const float *mips;
+    float *img;
+    Counters *cnt;
+    int tiles_x, split;
+    int count_frag;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void splat_mid_kernel(TileArgs a) {
+    constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
+    constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) double smem_d[];
+    double *tile = smem_d;                                                   // [C][MTILE_H][MSTR]
+    float *T = reinterpret_cast<float *>(tile + C * MTILE_H * MSTR);         // mip pyramid, 5440 floats
+    __shared__ long long s_seg_off[256];
+    __shared__ int s_seg_cnt[256];
+    __shared__ int s_wcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int R = a.cam.R;
+    const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
+    const int tx0 = (tile_id % a.tiles_x) * TILE, ty0 = (tile_id / a.tiles_x) * MTILE_H;
+    const float fx0 = (float)tx0, fy0 = (float)ty0, fx1 = (float)(tx0 + TILE), fy1 = (float)(ty0 + MTILE_H);
+    for (int i = tid; i < MIP_TOTAL; i += 256) T[i] = a.mips[i];
+    for (int i = tid; i < C * MTILE_H * MSTR; i += 256) tile[i] = 0.0;
+    __syncthreads();
+    const int lx = lane & 7, ly = lane >> 3;
+    unsigned long long n_frag = 0;
+    bool touched = false;
+
+    // segment headers are examined 256 at a time (one per lane); batches are dealt round-robin to the
+    // `split` workgroups of this tile
+    for (int sbase = sp * 256; sbase < a.n_chunks; sbase += a.split * 256) {
+        const int seg = sbase + tid;
+        bool shit = false;
+        int scnt = 0;
+        if (seg < a.n_chunks) {
+            scnt = a.seg_count[seg];
+            if (scnt > 0) {
+                const float4 bb = a.seg_bbox[seg];
+                shit = bb.x < fx1 && bb.z > fx0 && bb.y < fy1 && bb.w > fy0;
+            }
+        }
+        const unsigned long long smask = __ballot(shit);
+        const int sbefore = __popcll(smask & ((1ull << lane) - 1ull));
+        __syncthreads();                       // previous batch's segment list is no longer read
+        if (lane == 0) s_wcnt[wv] = __popcll(smask);
+        __syncthreads();
+        int wbase = 0, nseg = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wv) wbase += s_wcnt[w];
+            nseg += s_wcnt[w];
+        }
+        if (shit) {
+            s_seg_off[wbase + sbefore] = a.seg_offset[seg];
+            s_seg_cnt[wbase + sbefore] = scnt;
+        }
+        __syncthreads();
+        for (int sidx = 0; sidx < nseg; ++sidx) {
+            const long long off = s_seg_off[sidx];
+            const int cnt = s_seg_cnt[sidx];
+            for (int base = 0; base < cnt; base += 256) {
+                const int li = base + tid;
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                float gw1 = 0.f, gw2 = 0.f;
+                bool hit = false;
+                if (li < cnt && off + li < a.n_records) {
+                    g = a.geom[off + li];
+                    gw1 = a.w[(off + li) * NW];
+                    if (NW == 2) gw2 = a.w[(off + li) * NW + 1];
+                    const float half = 0.5f * g.z;
+                    hit = (g.x + half > fx0) && (g.x - half < fx1) && (g.y + half > fy0) && (g.y - half < fy1);
+                }
+                unsigned long long mask = __ballot(hit);
+                while (mask) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    Proj q;
+                    q.pcx = __shfl(g.x, src); q.pcy = __shfl(g.y, src); q.P = __shfl(g.z, src);
+                    const float w0 = __shfl(g.w, src), w1 = __shfl(gw1, src);
+                    const float w2 = (NW == 2) ? __shfl(gw2, src) : 0.0f;
+                    q.half = 0.5f * q.P; q.invP = 1.0f / q.P;
+                    int ilo, ihi, jlo, jhi;
+                    cover_range(q.pcx, q.half, R, ilo, ihi);
+                    cover_range(q.pcy, q.half, R, jlo, jhi);
+                    ilo = max(ilo, tx0); ihi = min(ihi, tx0 + TILE - 1);
+                    jlo = max(jlo, ty0); jhi = min(jhi, ty0 + MTILE_H - 1);
+                    if (ilo > ihi || jlo > jhi) continue;
+                    touched = true;
+                    const int lvl = level_for(q.P);
+                    const int n = 64 >> lvl, toff = mip_offset(lvl);
+                    for (int jb = jlo; jb <= jhi; jb += 8) {
+                        const int j = jb + ly;
+                        const float dy = ((float)j + 0.5f) - q.pcy;
+                        const int ty = nearest_index((dy + q.half) * q.invP, n);
+                        for (int ib = ilo; ib <= ihi; ib += 8) {
+                            const int i = ib + lx;
+                            if (i <= ihi && j <= jhi) {
+                                const float dx = ((float)i + 0.5f) - q.pcx;
+                                const int tx = nearest_index((dx + q.half) * q.invP, n);
+                                const float kv = T[toff + ty * n + tx];
+                                double *d = tile + (j - ty0) * MSTR + (i - tx0);
+                                if (MODE == TSP_MODE_RGB) {
+                                    latomic_add(d, kv * w0); latomic_add(d + MTILE_H * MSTR, kv * w1);
+                                    latomic_add(d + 2 * MTILE_H * MSTR, kv * w2); latomic_add(d + 3 * MTILE_H * MSTR, 1.0f);
+                                } else {
+                                    const float val = kv * w0;
+                                    latomic_add(d, val); latomic_add(d + MTILE_H * MSTR, val * w1);
+                                }
+                            }
+                        }
+                    }
+                    if (a.count_frag && lane == 0) n_frag += (unsigned long long)((ihi - ilo + 1) * (jhi - jlo + 1));
+                }
+            }
+        }
+    }
+    const int any = __syncthreads_or(touched ? 1 : 0);
+    if (any) {
+        for (int idx = tid; idx < TILE * MTILE_H; idx += 256) {
+            const int wy = idx / TILE, wx = idx % TILE;
+            const int gx = tx0 + wx, gy = ty0 + wy;
+            if (gx < R && gy < R) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const double v = tile[c * MTILE_H * MSTR + wy * MSTR + wx];
+                    if (v != 0.0) gatomic_add(a.img + ((size_t)gy * R + gx) * C + c, (float)v);
+                }
+            }
+        }
+    }
+    if (a.count_frag && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel H: huge footprints (P >= 64 px), tile gather with bilinear sampling
+// ---------------------------------------------------------------------------------------------
+constexpr int HT = 512;              // threads per workgroup of kernel H (8 waves share one quad table)
+constexpr int HTILE_W = 128;         // its tile: 128 x 64 pixels, 4x4 pixels per lane
+
+template <int MODE>
+__global__ __launch_bounds__(HT) void splat_huge_kernel(TileArgs a) {
+    constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
+    constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
+    constexpr int NA = (MODE == TSP_MODE_RGB) ? 3 : 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // quad table: Q[j][i] = (T[j][i], T[j][i+1], T[j+1][i], T[j+1][i+1]) with +1 clamped to 63, so one
+    // ds_read_b128 fetches the whole bilinear stencil; the 64-float4 row stride keeps the 16-lane
+    // groups of ds_read_b128 on distinct 16-byte slots when neighbouring lanes step one texel
+    float4 *Q = reinterpret_cast<float4 *>(smem);                 // [64][64]
+    float4 *qg = Q + 64 * 64;                                     // queue: (pcx, pcy, half, 1/P)  [256]
+    float4 *qw = qg + 256;                                        // queue: (w0, w1, w2, -)        [256]
+    __shared__ int s_wcnt[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int R = a.cam.R;
+    const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
+    const int tx0 = (tile_id % a.tiles_x) * HTILE_W, ty0 = (tile_id / a.tiles_x) * TILE;
+    const float fx0 = (float)tx0, fy0 = (float)ty0, fx1 = (float)(tx0 + HTILE_W), fy1 = (float)(ty0 + TILE);
+    for (int i = tid; i < 64 * 64; i += HT) {
+        const int j = i >> 6, x = i & 63, j1 = min(j + 1, 63), x1 = min(x + 1, 63);
+        Q[i] = make_float4(a.mips[j * 64 + x], a.mips[j * 64 + x1], a.mips[j1 * 64 + x], a.mips[j1 * 64 + x1]);
+    }
+    const int bx = tid & 31, by = tid >> 5;           // 4x4 pixel block owned by this lane
+    const int px0 = tx0 + 4 * bx, py0 = ty0 + 4 * by;
+    // pixel-centre coordinates; pixels outside the image get +inf so they are never covered
+    float pxc[4], pyc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        pxc[t] = (px0 + t < R) ? (float)(px0 + t) + 0.5f : __builtin_inff();
+        pyc[t] = (py0 + t < R) ? (float)(py0 + t) + 0.5f : __builtin_inff();
+    }
+    float acc[16][NA], tot[16][NA];
+    float cnt_acc[16];               // rgb: fragment counter channel
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        cnt_acc[p] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NA; ++c) { acc[p][c] = 0.0f; tot[p][c] = 0.0f; }
+    }
+    unsigned long long n_frag = 0;
+    int since_fold = 0;
+    __syncthreads();
+
+    for (long long base = (long long)sp * 256; base < a.n_records; base += (long long)a.split * 256) {
+        // ---- waves 0-3 test 256 records against the tile and compact the hits into the LDS queue ----
+        const long long ri = base + tid;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool hit = false;
+        if (tid < 256 && ri < a.n_records) {
+            g = a.geom[ri];
+            const float half = 0.5f * g.z;
+            hit = (g.x + half > fx0) && (g.x - half < fx1) && (g.y + half > fy0) && (g.y - half < fy1);
+        }
+        const unsigned long long mask = __ballot(hit);
+        const int before = __popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0 && wv < 4) s_wcnt[wv] = __popcll(mask);
+        __syncthreads();
+        int wbase = 0, nq = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wv) wbase += s_wcnt[w];
+            nq += s_wcnt[w];
+        }
+        if (hit) {
+            qg[wbase + before] = make_float4(g.x, g.y, 0.5f * g.z, 1.0f / g.z);
+            const float w1 = a.w[ri * NW];
+            const float w2 = (NW == 2) ? a.w[ri * NW + 1] : 0.0f;
+            qw[wbase + before] = make_float4(g.w, (MODE == TSP_MODE_RGB) ? w1 : g.w * w1, w2, 0.0f);
+        }
+        __syncthreads();
+        // ---- every lane evaluates its 4x4 pixels for each queued footprint -------------------------
+        for (int e = 0; e < nq; ++e) {
+            const float4 r4 = qg[e];
+            const float4 wq = qw[e];
+            const float pcx = r4.x, pcy = r4.y, half = r4.z, invP = r4.w;
+            int col[4], row[4];
+            float fxs[4], fys[4], gxs[4], gys[4];
+            int ncov_x = 0, ncov_y = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                {   // canonical texel coordinate: u = (d + half) * invP ; tu = u * 64 - 0.5 (tsp_math.h)
+                    const float d = pxc[t] - pcx;
+                    const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                    const float u = (d + half) * invP;
+                    // clamping tu to [0, 63] reproduces clamp-to-edge: tu < 0 -> texel 0 weight 1,
+                    // tu in [63, 63.5) -> texel 63 (its quad holds T[63] twice)
+                    const float tu = __builtin_amdgcn_fmed3f(__builtin_fmaf(u, 64.0f, -0.5f), 0.0f, 63.0f);
+                    const float f0 = __builtin_floorf(tu);
+                    const float fr = (tu - f0) * cv;        // uncovered column: both weights 0
+                    col[t] = (int)f0;
+                    fxs[t] = fr;
+                    gxs[t] = cv - fr;
+                    ncov_x += (cv != 0.0f);
+                }
+                {
+                    const float d = pyc[t] - pcy;
+                    const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                    const float v = (d + half) * invP;
+                    const float tv = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, 64.0f, -0.5f), 0.0f, 63.0f);
+                    const float f0 = __builtin_floorf(tv);
+                    const float fr = (tv - f0) * cv;
+                    row[t] = ((int)f0) << 6;
+                    fys[t] = fr;
+                    gys[t] = cv - fr;
+                    ncov_y += (cv != 0.0f);
+                }
+            }
+#pragma unroll
+            for (int ty = 0; ty < 4; ++ty) {
+#pragma unroll
+                for (int tx = 0; tx < 4; ++tx) {
+                    const float4 q = Q[row[ty] + col[tx]];
+                    // T00*(1-fx) + T01*fx etc. in the cancellation-free form; each FMA differs from the
+                    // two-rounding form by <= 1 ulp of a sum of non-negative terms
+                    const float top = __builtin_fmaf(q.y, fxs[tx], q.x * gxs[tx]);
+                    const float bot = __builtin_fmaf(q.w, fxs[tx], q.z * gxs[tx]);
+                    const float kv = __builtin_fmaf(bot, fys[ty], top * gys[ty]);
+                    const int p = ty * 4 + tx;
+                    acc[p][0] = __builtin_fmaf(kv, wq.x, acc[p][0]);
+                    acc[p][1] = __builtin_fmaf(kv, wq.y, acc[p][1]);
+                    if (MODE == TSP_MODE_RGB) acc[p][NA - 1] = __builtin_fmaf(kv, wq.z, acc[p][NA - 1]);
+                }
+            }
+            if (MODE == TSP_MODE_RGB) {
+#pragma unroll
+                for (int ty = 0; ty < 4; ++ty)
+#pragma unroll
+                    for (int tx = 0; tx < 4; ++tx)
+                        cnt_acc[ty * 4 + tx] += (gys[ty] + fys[ty]) * (gxs[tx] + fxs[tx]);   // 1 iff covered
+            }
+            if (a.count_frag) n_frag += (unsigned long long)(ncov_x * ncov_y);
+            // fold the short-run accumulators into the totals every 64 footprints: bounds the
+            // float32 accumulation error at ~sqrt(64)*2^-24 per level instead of sqrt(n)
+            if (++since_fold == 64) {
+                since_fold = 0;
+#pragma unroll
+                for (int p = 0; p < 16; ++p)
+#pragma unroll
+                    for (int c = 0; c < NA; ++c) { tot[p][c] += acc[p][c]; acc[p][c] = 0.0f; }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- add this workgroup's partial tile into the render target ---------------------------------
+#pragma unroll
+    for (int ty = 0; ty < 4; ++ty) {
+#pragma unroll
+        for (int tx = 0; tx < 4; ++tx) {
+            const int p = ty * 4 + tx, gx = px0 + tx, gy = py0 + ty;
+            if (gx < R && gy < R) {
+                float *d = a.img + ((size_t)gy * R + gx) * C;
+#pragma unroll
+                for (int c = 0; c < NA; ++c) {
+                    const float v = tot[p][c] + acc[p][c];
+                    if (v != 0.0f) gatomic_add(d + c, v);
+                }
+                if (MODE == TSP_MODE_RGB && cnt_acc[p] != 0.0f) gatomic_add(d + 3, cnt_acc[p]);
+            }
+        }
+    }
+    if (a.count_frag) {
+        for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
+        if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int grow(void **p, int64_t *cap, int64_t need, size_t elem) {
+    if (*cap >= need) return TSP_OK;
+    if (*p) TSP_HIP(hipFree(*p));
+    *p = nullptr;
+    TSP_HIP(hipMalloc(p, (size_t)need * elem));
+    *cap = need;
+    return TSP_OK;
+}
+
+template <int MODE>
+static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_starts, const int64_t *h_lens, int n_ranges,
+                        int64_t total) {
+    constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
+    constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
+    Workspace &ws = ctx->ws;
+    hipStream_t st = ctx->stream;
+
+    // ranges -> chunks
     std::vector<int64_t> pack(3 * (size_t)n_ranges + 1);
-    int64_t acc = 0;
+    int64_t n_chunks64 = 0;
     for (int i = 0; i < n_ranges; ++i) {
         pack[i] = h_starts[i];
         pack[n_ranges + i] = h_lens[i];
-        pack[2 * n_ranges + i] = acc;
-        acc += h_lens[i];
+        pack[2 * n_ranges + i] = n_chunks64;
+        n_chunks64 += (h_lens[i] + CHUNK - 1) / CHUNK;
     }
-    pack[3 * n_ranges] = acc;
-    if (ctx->ws.range_capacity < (int64_t)pack.size()) {
-        if (ctx->ws.range_prefix) TSP_HIP(hipFree(ctx->ws.range_prefix));
-        ctx->ws.range_capacity = (int64_t)pack.size() * 2 + 64;
-        TSP_HIP(hipMalloc((void **)&ctx->ws.range_prefix, ctx->ws.range_capacity * sizeof(int64_t)));
+    pack[3 * n_ranges] = n_chunks64;
+    TSP_REQUIRE(n_chunks64 < (1ll << 30), TSP_EINVAL, "too many chunks");
+    const int n_chunks = (int)n_chunks64;
+    if (ws.range_capacity < (int64_t)pack.size()) {
+        if (ws.range_prefix) TSP_HIP(hipFree(ws.range_prefix));
+        ws.range_capacity = (int64_t)pack.size() * 2 + 64;
+        TSP_HIP(hipMalloc((void **)&ws.range_prefix, ws.range_capacity * sizeof(int64_t)));
     }
-    TSP_HIP(hipMemcpyAsync(ctx->ws.range_prefix, pack.data(), pack.size() * sizeof(int64_t), hipMemcpyHostToDevice,
-                           ctx->stream));
-    int rc = launch_generic(ctx, cam, ctx->ws.range_prefix, n_ranges, total, mode);
-    TSP_HIP(hipStreamSynchronize(ctx->stream));
-    return rc;
+    TSP_HIP(hipMemcpyAsync(ws.range_prefix, pack.data(), pack.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    // per-chunk segment table
+    if (ws.seg_capacity < n_chunks) {
+        if (ws.seg_count) TSP_HIP(hipFree(ws.seg_count));
+        if (ws.seg_offset) TSP_HIP(hipFree(ws.seg_offset));
+        if (ws.seg_bbox) TSP_HIP(hipFree(ws.seg_bbox));
+        ws.seg_capacity = (int64_t)n_chunks + n_chunks / 4 + 64;
+        TSP_HIP(hipMalloc((void **)&ws.seg_count, ws.seg_capacity * sizeof(int)));
+        TSP_HIP(hipMalloc((void **)&ws.seg_offset, ws.seg_capacity * sizeof(long long)));
+        TSP_HIP(hipMalloc((void **)&ws.seg_bbox, ws.seg_capacity * sizeof(float4)));
+    }
+    // record lists: start modest, grow to the exact need when a frame overflows (rare)
+    int rc;
+    if (ws.mid_capacity == 0) {
+        const int64_t guess = std::max<int64_t>(total / 4, 1 << 16);
+        if ((rc = grow(&ws.mid_geom, &ws.mid_capacity, guess, sizeof(float4)))) return rc;
+        if (ws.mid_w) TSP_HIP(hipFree(ws.mid_w));
+        TSP_HIP(hipMalloc(&ws.mid_w, (size_t)ws.mid_capacity * 2 * sizeof(float)));
+    }
+    if (ws.huge_capacity == 0) {
+        const int64_t guess = std::max<int64_t>(total / 16, 1 << 16);
+        if ((rc = grow(&ws.huge_geom, &ws.huge_capacity, guess, sizeof(float4)))) return rc;
+        if (ws.huge_w) TSP_HIP(hipFree(ws.huge_w));
+        TSP_HIP(hipMalloc(&ws.huge_w, (size_t)ws.huge_capacity * 2 * sizeof(float)));
+    }
+
+    Particles parts = ctx->p;
+    if (!ctx->use_quantity) parts.q = nullptr;
+    const int tiles_x = (ctx->R + TILE - 1) / TILE, n_tiles = tiles_x * tiles_x;
+    constexpr int WIN = WinSize<MODE>::value;
+    const size_t smem_s = (size_t)C * WIN * WIN * sizeof(double) + 64 * sizeof(float);
+    const size_t smem_m = (size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float);
+    const int mtiles_y = (ctx->R + MTILE_H - 1) / MTILE_H;
+    const size_t smem_h = (size_t)(64 * 64 + 512) * sizeof(float4);
+    static bool attr_set[3] = {false, false, false};
+    if (!attr_set[MODE]) {
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_huge_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h));
+        attr_set[MODE] = true;
+    }
+
+    Counters hc, carry;
+    memset(&carry, 0, sizeof(carry));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        StreamArgs sa;
+        sa.p = parts;
+        sa.ranges = ws.range_prefix; sa.n_ranges = n_ranges; sa.n_chunks = n_chunks;
+        const int max_blocks = ctx->cu_count * ctx->stream_blocks_per_cu;
+        sa.chunks_per_block = std::max(1, (n_chunks + max_blocks - 1) / max_blocks);
+        const int grid_s = (n_chunks + sa.chunks_per_block - 1) / sa.chunks_per_block;
+        sa.cam = cam; sa.mips = ctx->mips; sa.img = ctx->image;
+        sa.mid_geom = (float4 *)ws.mid_geom; sa.mid_w = (float *)ws.mid_w; sa.mid_capacity = ws.mid_capacity;
+        sa.huge_geom = (float4 *)ws.huge_geom; sa.huge_w = (float *)ws.huge_w; sa.huge_capacity = ws.huge_capacity;
+        sa.seg_count = ws.seg_count; sa.seg_offset = ws.seg_offset; sa.seg_bbox = ws.seg_bbox;
+        sa.cnt = ctx->counters; sa.p_small = ctx->p_small; sa.count_frag = ctx->count_fragments ? 1 : 0;
+        sa.emit_small = attempt == 0 ? 1 : 0;
+        TSP_HIP(hipEventRecord(ctx->ev[2], st));
+        hipLaunchKernelGGL(splat_stream_kernel<MODE>, dim3(grid_s), dim3(256), smem_s, st, sa);
+        TSP_HIP(hipGetLastError());
+        TSP_HIP(hipEventRecord(ctx->ev[3], st));
+        // the record counts size the two tile launches (and reveal a list overflow)
+        TSP_HIP(hipMemcpyAsync(&hc, ctx->counters, sizeof(hc), hipMemcpyDeviceToHost, st));
+        TSP_HIP(hipStreamSynchronize(st));
+        const bool mid_over = (int64_t)hc.n_mid > ws.mid_capacity, huge_over = (int64_t)hc.n_huge > ws.huge_capacity;
+        if (!mid_over && !huge_over) break;
+        TSP_REQUIRE(attempt == 0, TSP_ENOMEM, "record lists overflowed twice");
+        // enlarge and replay kernel S in records-only mode (its small footprints are already in the image)
+        if (mid_over) {
+            if ((rc = grow(&ws.mid_geom, &ws.mid_capacity, (int64_t)hc.n_mid + (int64_t)hc.n_mid / 8 + 1024, sizeof(float4)))) return rc;
+            if (ws.mid_w) TSP_HIP(hipFree(ws.mid_w));
+            TSP_HIP(hipMalloc(&ws.mid_w, (size_t)ws.mid_capacity * 2 * sizeof(float)));
+        }
+        if (huge_over) {
+            if ((rc = grow(&ws.huge_geom, &ws.huge_capacity, (int64_t)hc.n_huge + (int64_t)hc.n_huge / 8 + 1024, sizeof(float4)))) return rc;
+            if (ws.huge_w) TSP_HIP(hipFree(ws.huge_w));
+            TSP_HIP(hipMalloc(&ws.huge_w, (size_t)ws.huge_capacity * 2 * sizeof(float)));
+        }
+        TSP_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(Counters), st));
+        carry = hc;
+    }
+
+    if (carry.n_small || carry.n_fragments) {   // statistics of the first attempt (its small footprints stand)
+        hc.n_small += carry.n_small;
+        hc.n_fragments += carry.n_fragments;
+        TSP_HIP(hipMemcpyAsync(ctx->counters, &hc, sizeof(hc), hipMemcpyHostToDevice, st));
+        TSP_HIP(hipStreamSynchronize(st));
+    }
+    TileArgs ta;
+    ta.seg_count = ws.seg_count; ta.seg_offset = ws.seg_offset; ta.seg_bbox = ws.seg_bbox; ta.n_chunks = n_chunks;
+    ta.cam = cam; ta.mips = ctx->mips; ta.img = ctx->image; ta.cnt = ctx->counters; ta.tiles_x = tiles_x;
+    ta.count_frag = ctx->count_fragments ? 1 : 0;
+    TSP_HIP(hipEventRecord(ctx->ev[4], st));
+    if (hc.n_mid > 0) {
+        ta.geom = (const float4 *)ws.mid_geom; ta.w = (const float *)ws.mid_w; ta.n_records = (long long)hc.n_mid;
+        ta.split = ctx->mid_split;
+        hipLaunchKernelGGL(splat_mid_kernel<MODE>, dim3(tiles_x * mtiles_y * ta.split), dim3(256), smem_m, st, ta);
+        TSP_HIP(hipGetLastError());
+    }
+    TSP_HIP(hipEventRecord(ctx->ev[5], st));
+    if (hc.n_huge > 0) {
+        ta.geom = (const float4 *)ws.huge_geom; ta.w = (const float *)ws.huge_w; ta.n_records = (long long)hc.n_huge;
+        // enough splits to give every CU several workgroups, but never more than there are batches
+        const long long batches = ((long long)hc.n_huge + 255) / 256;
+        const int htiles_x = (ctx->R + HTILE_W - 1) / HTILE_W, htiles = htiles_x * tiles_x;
+        int split = ctx->huge_split;
+        if (split <= 0) split = std::max(1, (ctx->cu_count * 16 + htiles - 1) / htiles);
+        split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
+        ta.split = split;
+        ta.tiles_x = htiles_x;
+        hipLaunchKernelGGL(splat_huge_kernel<MODE>, dim3(htiles * split), dim3(HT), smem_h, st, ta);
+        TSP_HIP(hipGetLastError());
+    }
+    TSP_HIP(hipEventRecord(ctx->ev[6], st));
+    TSP_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_stream = ms;
+    TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->stats.ms_mid = ms;
+    TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6])); ctx->stats.ms_huge = ms;
+    return TSP_OK;
+}
+
+int launch_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_starts, const int64_t *h_lens, int n_ranges,
+                    int64_t total, int mode) {
+    switch (mode) {
+        case TSP_MODE_WEIGHTED: return run_pipeline<TSP_MODE_WEIGHTED>(ctx, cam, h_starts, h_lens, n_ranges, total);
+        case TSP_MODE_DEPTH: return run_pipeline<TSP_MODE_DEPTH>(ctx, cam, h_starts, h_lens, n_ranges, total);
+        case TSP_MODE_RGB: return run_pipeline<TSP_MODE_RGB>(ctx, cam, h_starts, h_lens, n_ranges, total);
+    }
+    set_error("bad mode %d", mode);
+    return TSP_EINVAL;
 }
 
 }  // namespace tsp
