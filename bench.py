@@ -165,21 +165,33 @@ def main():
     bytes_per_launch = B_ALG[args.mode] * n_per
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     stream_ms = means["stream"] if means["stream"] > 0 else means["total"]
+    workload_name = (f"{n_total:.4g} dm particles ({n_per:.4g}/GPU), {args.mode}, {R}^2 buffer, camera A "
+                     f"(scale {args.scale:g}), reference TestDataLoader h-law"
+                     + (f", h capped at {args.h_cap_px:g} px" if args.h_cap_px > 0 else "")
+                     + ", splat + " + ("RCCL image reduce + " if world > 1 else "") + "colormap")
     measured_peak = ctx.measure_read_bandwidth(1 << 30, 10)
+    # HBM bytes of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE doubled as
+    # MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); null when no profile matches this workload
+    traffic = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "latest_bench_counters.json")))
+        if prof.get("bench_line", {}).get("config", {}).get("workload") == workload_name:
+            for k, v in prof["per_kernel"].items():
+                if dom in k:
+                    traffic = (v.get("hbm_read_bytes_corrected", 0.0) + v.get("hbm_write_bytes", 0.0)) / 1e9
+    except Exception:
+        pass
     result = {
         "metric": "particles/sec splatted to 1024^2 buffer",
         "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{n_total:.4g} dm particles ({n_per:.4g}/GPU), {args.mode}, {R}^2 buffer, camera A "
-                               f"(scale {args.scale:g}), reference TestDataLoader h-law"
-                               + (f", h capped at {args.h_cap_px:g} px" if args.h_cap_px > 0 else "")
-                               + ", splat + " + ("RCCL image reduce + " if world > 1 else "") + "colormap",
+        "config": {"workload": workload_name,
                    "particles_per_gpu": n_per, "resolution": R, "sharding": f"index-range x{world}",
                    "pipeline": "generic" if args.generic else "three-class",
                    "fragments_per_particle": frags / n_total, "frames_per_s": 1e3 / ms_per_step},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": dom_ms,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "GB per launch (PMC)", "kernel_ms": dom_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "measured_read_peak_GBps": measured_peak,
                      "stream_kernel_ms": stream_ms,
@@ -216,13 +228,15 @@ def cpu_baseline(args, n_total, M, sf, R):
         oracle_c.splat(d["x"], d["y"], d["z"], d["h"], d["mass"], None, None, mode=0, M=M, sf=float(sf), R=R, mips=mips)
         return time.perf_counter() - t
 
-    pilot_n = 20000
-    d = sample(pilot_n)
-    run(d)
-    pilot = run(d)
-    n_s = int(min(max(pilot_n * args.cpu_seconds / max(pilot, 1e-4), pilot_n), 5e7, n_total))
+    # grow the sample until the oracle needs >= ~cpu_seconds/2 of wall time (bounded: <= 5e7 particles)
+    n_s = 200000
     d = sample(n_s)
+    run(d)                                   # warm-up (page faults of the per-thread images)
     secs = run(d)
+    while secs < 0.5 * args.cpu_seconds and n_s < min(5e7, n_total):
+        n_s = int(min(n_s * max(2.0, 0.8 * args.cpu_seconds / max(secs, 1e-3)), 5e7, n_total))
+        d = sample(n_s)
+        secs = run(d)
     return {"value": n_s / secs, "unit": "particles/s", "cores": cores, "kind": "port",
             "sample": f"{n_s} particles (uniform sample of the {n_total:.4g}-particle snapshot, same camera, {R}^2, "
                       f"density), oracle/oracle.c OpenMP, {secs:.1f} s"}

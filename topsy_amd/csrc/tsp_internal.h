@@ -87,9 +87,9 @@ struct tsp_context {
     tsp_stats stats = {};
     bool count_fragments = false;
     // pipeline tuning (tsp_set_option)
-    float p_small = 4.0f;             // footprints narrower than this many pixels are splatted by kernel S
-    int mid_split = 16, huge_split = 0;  // workgroups per image tile (0 = auto)
-    int stream_blocks_per_cu = 4;
+    float p_small = 11.3f;             // footprints narrower than this many pixels are splatted by kernel S
+    int mid_split = 128, huge_split = 0;  // workgroups per image tile (0 = auto)
+    int stream_blocks_per_cu = 8;
     int cu_count = 256;
     // RCCL
     void *comm = nullptr;

@@ -32,7 +32,7 @@
 
 namespace tsp {
 
-constexpr int CHUNK = 2048;          // particles per chunk
+constexpr int CHUNK = 1024;          // particles per chunk
 constexpr int KPT = CHUNK / 256;     // particles per thread per chunk
 constexpr int TILE = 64;             // image tile edge of kernel H (and tile width of kernel M)
 constexpr int MTILE_H = 32;          // tile height of kernel M (64 x 32 pixels per workgroup)
@@ -87,14 +87,16 @@ struct StreamArgs {
     int emit_small;            // 0: records only (replay after a record-list overflow)
 };
 
-template <int MODE>
-__global__ __launch_bounds__(256) void splat_stream_kernel(StreamArgs a) {
+// WC = channels kept in the LDS window: 1 for a density-only render (channel 1 is identically 0:
+// half the LDS and half the atomics), else the image's channel count.
+template <int MODE, int WC>
+__global__ __launch_bounds__(256, 4) void splat_stream_kernel(StreamArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;      // extra weights per record
     constexpr int WIN = WinSize<MODE>::value;
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
-    double *win = smem_d;                                            // [C][WIN*WIN]
-    float *T3 = reinterpret_cast<float *>(win + C * WIN * WIN);      // mip level 3: 8x8
+    double *win = smem_d;                                            // [WC][WIN*WIN]
+    float *T3 = reinterpret_cast<float *>(win + WC * WIN * WIN);     // mip level 3: 8x8
     __shared__ float s_red[4][4];
     __shared__ int s_cnt[4][2];
     __shared__ long long s_base[2];
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void splat_stream_kernel(StreamArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Camera &cam = a.cam;
     const int R = cam.R;
-    for (int i = tid; i < C * WIN * WIN; i += 256) win[i] = 0.0;
+    for (int i = tid; i < WC * WIN * WIN; i += 256) win[i] = 0.0;
     if (tid < 64) T3[tid] = a.mips[5376 + tid];
     __syncthreads();
 
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void splat_stream_kernel(StreamArgs a) {
                 const int gx = wox + wx, gy = woy + wy;
                 const int o = wy * WIN + wx;
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
+                for (int c = 0; c < WC; ++c) {
                     const double v = win[c * WIN * WIN + o];
                     if (v != 0.0) {
                         if (gx < R && gy < R) gatomic_add(a.img + ((size_t)gy * R + gx) * C + c, (float)v);
@@ -293,10 +295,12 @@ __global__ __launch_bounds__(256) void splat_stream_kernel(StreamArgs a) {
                         const float v1 = val * w1[k];
                         if (inw) {
                             double *d = win + wy * WIN + wx;
-                            latomic_add(d, val); latomic_add(d + WIN * WIN, v1);
+                            latomic_add(d, val);
+                            if (WC > 1) latomic_add(d + WIN * WIN, v1);
                         } else {
                             float *d = a.img + ((size_t)j * R + i) * C;
-                            gatomic_add(d, val); gatomic_add(d + 1, v1);
+                            gatomic_add(d, val);
+                            if (WC > 1) gatomic_add(d + 1, v1);
                         }
                     }
                 }
@@ -359,32 +363,35 @@ struct TileArgs {
     int count_frag;
 };
 
+constexpr int MT = 512;              // threads per workgroup of kernel M (8 waves share tile + LUT)
+
 template <int MODE>
-__global__ __launch_bounds__(256) void splat_mid_kernel(TileArgs a) {
+__global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
     double *tile = smem_d;                                                   // [C][MTILE_H][MSTR]
     float *T = reinterpret_cast<float *>(tile + C * MTILE_H * MSTR);         // mip pyramid, 5440 floats
-    __shared__ long long s_seg_off[256];
-    __shared__ int s_seg_cnt[256];
-    __shared__ int s_wcnt[4];
+    __shared__ long long s_seg_off[MT];
+    __shared__ int s_seg_cnt[MT];
+    __shared__ int s_wcnt[MT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int R = a.cam.R;
     const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
     const int tx0 = (tile_id % a.tiles_x) * TILE, ty0 = (tile_id / a.tiles_x) * MTILE_H;
     const float fx0 = (float)tx0, fy0 = (float)ty0, fx1 = (float)(tx0 + TILE), fy1 = (float)(ty0 + MTILE_H);
-    for (int i = tid; i < MIP_TOTAL; i += 256) T[i] = a.mips[i];
-    for (int i = tid; i < C * MTILE_H * MSTR; i += 256) tile[i] = 0.0;
+    for (int i = tid; i < MIP_TOTAL; i += MT) T[i] = a.mips[i];
+    for (int i = tid; i < C * MTILE_H * MSTR; i += MT) tile[i] = 0.0;
     __syncthreads();
     const int lx = lane & 7, ly = lane >> 3;
     unsigned long long n_frag = 0;
     bool touched = false;
 
-    // segment headers are examined 256 at a time (one per lane); batches are dealt round-robin to the
-    // `split` workgroups of this tile
-    for (int sbase = sp * 256; sbase < a.n_chunks; sbase += a.split * 256) {
-        const int seg = sbase + tid;
+    // segment headers are examined 256 at a time (one per lane).  Consecutive segments are spatial
+    // neighbours, so they are dealt to the `split` workgroups of this tile with stride `split`:
+    // every workgroup sees a uniform sample of the tile's segments (an even share of its work)
+    for (int sbase = 0; sbase * a.split < a.n_chunks; sbase += MT) {
+        const int seg = (sbase + tid) * a.split + sp;
         bool shit = false;
         int scnt = 0;
         if (seg < a.n_chunks) {
@@ -401,7 +408,7 @@ __global__ __launch_bounds__(256) void splat_mid_kernel(TileArgs a) {
         __syncthreads();
         int wbase = 0, nseg = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < MT / 64; ++w) {
             if (w < wv) wbase += s_wcnt[w];
             nseg += s_wcnt[w];
         }
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(256) void splat_mid_kernel(TileArgs a) {
         for (int sidx = 0; sidx < nseg; ++sidx) {
             const long long off = s_seg_off[sidx];
             const int cnt = s_seg_cnt[sidx];
-            for (int base = 0; base < cnt; base += 256) {
+            for (int base = 0; base < cnt; base += MT) {
                 const int li = base + tid;
                 float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
                 float gw1 = 0.f, gw2 = 0.f;
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(256) void splat_mid_kernel(TileArgs a) {
     }
     const int any = __syncthreads_or(touched ? 1 : 0);
     if (any) {
-        for (int idx = tid; idx < TILE * MTILE_H; idx += 256) {
+        for (int idx = tid; idx < TILE * MTILE_H; idx += MT) {
             const int wy = idx / TILE, wx = idx % TILE;
             const int gx = tx0 + wx, gy = ty0 + wy;
             if (gx < R && gy < R) {
@@ -490,13 +497,18 @@ __global__ __launch_bounds__(256) void splat_mid_kernel(TileArgs a) {
 // kernel H: huge footprints (P >= 64 px), tile gather with bilinear sampling
 // ---------------------------------------------------------------------------------------------
 constexpr int HT = 512;              // threads per workgroup of kernel H (8 waves share one quad table)
-constexpr int HTILE_W = 128;         // its tile: 128 x 64 pixels, 4x4 pixels per lane
+constexpr int HTILE_W = 128;         // its tile is 128 pixels wide: 32 lanes x 4 pixels
 
-template <int MODE>
-__global__ __launch_bounds__(HT) void splat_huge_kernel(TileArgs a) {
+// NACC = value channels accumulated (1: density only, 2: density + weighted/depth, 3: rgb);
+// PXH  = pixel rows per lane (4 or 8): the per-axis setup (12 instructions per row/column) is shared
+//        by 4*PXH pixels, so the taller block costs ~30 % fewer instructions per pixel; it is used
+//        when the accumulators still fit the 128-VGPR budget of a 512-thread workgroup (NACC == 1).
+template <int MODE, int NACC, int PXH>
+__global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
-    constexpr int NA = (MODE == TSP_MODE_RGB) ? 3 : 2;
+    constexpr int NPX = 4 * PXH;
+    constexpr int HTILE_H = 16 * PXH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // quad table: Q[j][i] = (T[j][i], T[j][i+1], T[j+1][i], T[j+1][i+1]) with +1 clamped to 63, so one
     // ds_read_b128 fetches the whole bilinear stencil; the 64-float4 row stride keeps the 16-lane
@@ -509,29 +521,38 @@ __global__ __launch_bounds__(HT) void splat_huge_kernel(TileArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int R = a.cam.R;
     const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
-    const int tx0 = (tile_id % a.tiles_x) * HTILE_W, ty0 = (tile_id / a.tiles_x) * TILE;
-    const float fx0 = (float)tx0, fy0 = (float)ty0, fx1 = (float)(tx0 + HTILE_W), fy1 = (float)(ty0 + TILE);
+    const int tx0 = (tile_id % a.tiles_x) * HTILE_W, ty0 = (tile_id / a.tiles_x) * HTILE_H;
+    const float fx0 = (float)tx0, fy0 = (float)ty0, fx1 = (float)(tx0 + HTILE_W), fy1 = (float)(ty0 + HTILE_H);
     for (int i = tid; i < 64 * 64; i += HT) {
         const int j = i >> 6, x = i & 63, j1 = min(j + 1, 63), x1 = min(x + 1, 63);
         Q[i] = make_float4(a.mips[j * 64 + x], a.mips[j * 64 + x1], a.mips[j1 * 64 + x], a.mips[j1 * 64 + x1]);
     }
-    const int bx = tid & 31, by = tid >> 5;           // 4x4 pixel block owned by this lane
-    const int px0 = tx0 + 4 * bx, py0 = ty0 + 4 * by;
+    const int bx = tid & 31, by = tid >> 5;           // 4 x PXH pixel block owned by this lane
+    const int px0 = tx0 + 4 * bx, py0 = ty0 + PXH * by;
     // pixel-centre coordinates; pixels outside the image get +inf so they are never covered
-    float pxc[4], pyc[4];
+    float pxc[4], pyc[PXH];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        pxc[t] = (px0 + t < R) ? (float)(px0 + t) + 0.5f : __builtin_inff();
-        pyc[t] = (py0 + t < R) ? (float)(py0 + t) + 0.5f : __builtin_inff();
-    }
-    float acc[16][NA], tot[16][NA];
-    float cnt_acc[16];               // rgb: fragment counter channel
+    for (int t = 0; t < 4; ++t) pxc[t] = (px0 + t < R) ? (float)(px0 + t) + 0.5f : __builtin_inff();
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
+    for (int t = 0; t < PXH; ++t) pyc[t] = (py0 + t < R) ? (float)(py0 + t) + 0.5f : __builtin_inff();
+    // Accumulation is two-level so the float32 error stays ~sqrt(run length) * 2^-24 instead of
+    // sqrt(n): short runs in `acc`, folded into `tot` (PXH == 4) or, when the registers are needed
+    // for the taller pixel block, straight into the render target (PXH == 8).
+    constexpr bool REG_TOTALS = (PXH == 4);
+    constexpr int NTOT = REG_TOTALS ? NPX : 1;
+    constexpr int FOLD_EVERY = REG_TOTALS ? 64 : 1024;
+    float acc[NPX][NACC], tot[NTOT][NACC];
+    float cnt_acc[NPX];              // rgb: fragment counter channel
+#pragma unroll
+    for (int p = 0; p < NPX; ++p) {
         cnt_acc[p] = 0.0f;
 #pragma unroll
-        for (int c = 0; c < NA; ++c) { acc[p][c] = 0.0f; tot[p][c] = 0.0f; }
+        for (int c = 0; c < NACC; ++c) acc[p][c] = 0.0f;
     }
+#pragma unroll
+    for (int p = 0; p < NTOT; ++p)
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) tot[p][c] = 0.0f;
     unsigned long long n_frag = 0;
     int since_fold = 0;
     __syncthreads();
@@ -563,45 +584,45 @@ __global__ __launch_bounds__(HT) void splat_huge_kernel(TileArgs a) {
             qw[wbase + before] = make_float4(g.w, (MODE == TSP_MODE_RGB) ? w1 : g.w * w1, w2, 0.0f);
         }
         __syncthreads();
-        // ---- every lane evaluates its 4x4 pixels for each queued footprint -------------------------
+        // ---- every lane evaluates its pixels for each queued footprint ------------------------------
         for (int e = 0; e < nq; ++e) {
             const float4 r4 = qg[e];
             const float4 wq = qw[e];
             const float pcx = r4.x, pcy = r4.y, half = r4.z, invP = r4.w;
-            int col[4], row[4];
-            float fxs[4], fys[4], gxs[4], gys[4];
+            int col[4], row[PXH];
+            float fxs[4], gxs[4], fys[PXH], gys[PXH];
             int ncov_x = 0, ncov_y = 0;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                {   // canonical texel coordinate: u = (d + half) * invP ; tu = u * 64 - 0.5 (tsp_math.h)
-                    const float d = pxc[t] - pcx;
-                    const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
-                    const float u = (d + half) * invP;
-                    // clamping tu to [0, 63] reproduces clamp-to-edge: tu < 0 -> texel 0 weight 1,
-                    // tu in [63, 63.5) -> texel 63 (its quad holds T[63] twice)
-                    const float tu = __builtin_amdgcn_fmed3f(__builtin_fmaf(u, 64.0f, -0.5f), 0.0f, 63.0f);
-                    const float f0 = __builtin_floorf(tu);
-                    const float fr = (tu - f0) * cv;        // uncovered column: both weights 0
-                    col[t] = (int)f0;
-                    fxs[t] = fr;
-                    gxs[t] = cv - fr;
-                    ncov_x += (cv != 0.0f);
-                }
-                {
-                    const float d = pyc[t] - pcy;
-                    const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
-                    const float v = (d + half) * invP;
-                    const float tv = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, 64.0f, -0.5f), 0.0f, 63.0f);
-                    const float f0 = __builtin_floorf(tv);
-                    const float fr = (tv - f0) * cv;
-                    row[t] = ((int)f0) << 6;
-                    fys[t] = fr;
-                    gys[t] = cv - fr;
-                    ncov_y += (cv != 0.0f);
-                }
+                // canonical texel coordinate: u = (d + half) * invP ; tu = u * 64 - 0.5 (tsp_math.h)
+                const float d = pxc[t] - pcx;
+                const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                const float u = (d + half) * invP;
+                // clamping tu to [0, 63] reproduces clamp-to-edge: tu < 0 -> texel 0 weight 1,
+                // tu in [63, 63.5) -> texel 63 (its quad holds T[63] twice)
+                const float tu = __builtin_amdgcn_fmed3f(__builtin_fmaf(u, 64.0f, -0.5f), 0.0f, 63.0f);
+                const float f0 = __builtin_floorf(tu);
+                const float fr = (tu - f0) * cv;        // uncovered column: both weights 0
+                col[t] = (int)f0;
+                fxs[t] = fr;
+                gxs[t] = cv - fr;
+                ncov_x += (cv != 0.0f);
             }
 #pragma unroll
-            for (int ty = 0; ty < 4; ++ty) {
+            for (int t = 0; t < PXH; ++t) {
+                const float d = pyc[t] - pcy;
+                const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                const float v = (d + half) * invP;
+                const float tv = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, 64.0f, -0.5f), 0.0f, 63.0f);
+                const float f0 = __builtin_floorf(tv);
+                const float fr = (tv - f0) * cv;
+                row[t] = ((int)f0) << 6;
+                fys[t] = fr;
+                gys[t] = cv - fr;
+                ncov_y += (cv != 0.0f);
+            }
+#pragma unroll
+            for (int ty = 0; ty < PXH; ++ty) {
 #pragma unroll
                 for (int tx = 0; tx < 4; ++tx) {
                     const float4 q = Q[row[ty] + col[tx]];
@@ -612,13 +633,16 @@ __global__ __launch_bounds__(HT) void splat_huge_kernel(TileArgs a) {
                     const float kv = __builtin_fmaf(bot, fys[ty], top * gys[ty]);
                     const int p = ty * 4 + tx;
                     acc[p][0] = __builtin_fmaf(kv, wq.x, acc[p][0]);
-                    acc[p][1] = __builtin_fmaf(kv, wq.y, acc[p][1]);
-                    if (MODE == TSP_MODE_RGB) acc[p][NA - 1] = __builtin_fmaf(kv, wq.z, acc[p][NA - 1]);
+                    if (NACC >= 2) acc[p][NACC >= 2 ? 1 : 0] = __builtin_fmaf(kv, wq.y, acc[p][NACC >= 2 ? 1 : 0]);
+                    if (NACC >= 3) acc[p][NACC - 1] = __builtin_fmaf(kv, wq.z, acc[p][NACC - 1]);
                 }
+                // keep at most one pixel row of quad loads (4 x 4 VGPRs) in flight: without this the
+                // scheduler hoists every ds_read_b128 of the block and spills
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (MODE == TSP_MODE_RGB) {
 #pragma unroll
-                for (int ty = 0; ty < 4; ++ty)
+                for (int ty = 0; ty < PXH; ++ty)
 #pragma unroll
                     for (int tx = 0; tx < 4; ++tx)
                         cnt_acc[ty * 4 + tx] += (gys[ty] + fys[ty]) * (gxs[tx] + fxs[tx]);   // 1 iff covered
@@ -626,27 +650,44 @@ __global__ __launch_bounds__(HT) void splat_huge_kernel(TileArgs a) {
             if (a.count_frag) n_frag += (unsigned long long)(ncov_x * ncov_y);
             // fold the short-run accumulators into the totals every 64 footprints: bounds the
             // float32 accumulation error at ~sqrt(64)*2^-24 per level instead of sqrt(n)
-            if (++since_fold == 64) {
+            if (++since_fold == FOLD_EVERY) {
                 since_fold = 0;
+                if (REG_TOTALS) {
 #pragma unroll
-                for (int p = 0; p < 16; ++p)
+                    for (int p = 0; p < NPX; ++p)
 #pragma unroll
-                    for (int c = 0; c < NA; ++c) { tot[p][c] += acc[p][c]; acc[p][c] = 0.0f; }
+                        for (int c = 0; c < NACC; ++c) { tot[p < NTOT ? p : 0][c] += acc[p][c]; acc[p][c] = 0.0f; }
+                } else {
+#pragma unroll
+                    for (int ty = 0; ty < PXH; ++ty)
+#pragma unroll
+                        for (int tx = 0; tx < 4; ++tx) {
+                            const int p = ty * 4 + tx;
+                            if (px0 + tx < R && py0 + ty < R) {
+                                float *d = a.img + ((size_t)(py0 + ty) * R + px0 + tx) * C;
+#pragma unroll
+                                for (int c = 0; c < NACC; ++c) {
+                                    if (acc[p][c] != 0.0f) gatomic_add(d + c, acc[p][c]);
+                                    acc[p][c] = 0.0f;
+                                }
+                            }
+                        }
+                }
             }
         }
         __syncthreads();
     }
     // ---- add this workgroup's partial tile into the render target ---------------------------------
 #pragma unroll
-    for (int ty = 0; ty < 4; ++ty) {
+    for (int ty = 0; ty < PXH; ++ty) {
 #pragma unroll
         for (int tx = 0; tx < 4; ++tx) {
             const int p = ty * 4 + tx, gx = px0 + tx, gy = py0 + ty;
             if (gx < R && gy < R) {
                 float *d = a.img + ((size_t)gy * R + gx) * C;
 #pragma unroll
-                for (int c = 0; c < NA; ++c) {
-                    const float v = tot[p][c] + acc[p][c];
+                for (int c = 0; c < NACC; ++c) {
+                    const float v = (REG_TOTALS ? tot[p < NTOT ? p : 0][c] : 0.0f) + acc[p][c];
                     if (v != 0.0f) gatomic_add(d + c, v);
                 }
                 if (MODE == TSP_MODE_RGB && cnt_acc[p] != 0.0f) gatomic_add(d + 3, cnt_acc[p]);
@@ -657,6 +698,28 @@ __global__ __launch_bounds__(HT) void splat_huge_kernel(TileArgs a) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
         if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
     }
+}
+
+template <int MODE, int NACC, int PXH>
+static int launch_huge(tsp_context *ctx, TileArgs ta, size_t smem_h, long long n_huge) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_huge_kernel<MODE, NACC, PXH>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h));
+        attr_set = true;
+    }
+    const int htiles_x = (ctx->R + HTILE_W - 1) / HTILE_W, htiles_y = (ctx->R + 16 * PXH - 1) / (16 * PXH);
+    const int htiles = htiles_x * htiles_y;
+    // enough splits to give every CU many workgroups, but never more than there are record batches
+    const long long batches = (n_huge + 255) / 256;
+    int split = ctx->huge_split;
+    if (split <= 0) split = std::max(1, (ctx->cu_count * 32 + htiles - 1) / htiles);
+    split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
+    ta.split = split;
+    ta.tiles_x = htiles_x;
+    hipLaunchKernelGGL((splat_huge_kernel<MODE, NACC, PXH>), dim3(htiles * split), dim3(HT), smem_h, ctx->stream, ta);
+    TSP_HIP(hipGetLastError());
+    return TSP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -726,15 +789,17 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     if (!ctx->use_quantity) parts.q = nullptr;
     const int tiles_x = (ctx->R + TILE - 1) / TILE, n_tiles = tiles_x * tiles_x;
     constexpr int WIN = WinSize<MODE>::value;
-    const size_t smem_s = (size_t)C * WIN * WIN * sizeof(double) + 64 * sizeof(float);
+    const bool second_channel = (MODE == TSP_MODE_DEPTH) || (MODE == TSP_MODE_RGB) || (ctx->p.q != nullptr && ctx->use_quantity);
+    const int WCr = (MODE == TSP_MODE_RGB) ? 4 : (second_channel ? 2 : 1);
+    const size_t smem_s = (size_t)WCr * WIN * WIN * sizeof(double) + 64 * sizeof(float);
     const size_t smem_m = (size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float);
     const int mtiles_y = (ctx->R + MTILE_H - 1) / MTILE_H;
     const size_t smem_h = (size_t)(64 * 64 + 512) * sizeof(float4);
     static bool attr_set[3] = {false, false, false};
     if (!attr_set[MODE]) {
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WIN * WIN * sizeof(double) + 256)));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WIN * WIN * sizeof(double) + 256)));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_huge_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h));
         attr_set[MODE] = true;
     }
 
@@ -754,7 +819,8 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         sa.cnt = ctx->counters; sa.p_small = ctx->p_small; sa.count_frag = ctx->count_fragments ? 1 : 0;
         sa.emit_small = attempt == 0 ? 1 : 0;
         TSP_HIP(hipEventRecord(ctx->ev[2], st));
-        hipLaunchKernelGGL(splat_stream_kernel<MODE>, dim3(grid_s), dim3(256), smem_s, st, sa);
+        if (WCr == 1) hipLaunchKernelGGL((splat_stream_kernel<MODE, 1>), dim3(grid_s), dim3(256), smem_s, st, sa);
+        else hipLaunchKernelGGL((splat_stream_kernel<MODE, C>), dim3(grid_s), dim3(256), smem_s, st, sa);
         TSP_HIP(hipGetLastError());
         TSP_HIP(hipEventRecord(ctx->ev[3], st));
         // the record counts size the two tile launches (and reveal a list overflow)
@@ -792,22 +858,16 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     if (hc.n_mid > 0) {
         ta.geom = (const float4 *)ws.mid_geom; ta.w = (const float *)ws.mid_w; ta.n_records = (long long)hc.n_mid;
         ta.split = ctx->mid_split;
-        hipLaunchKernelGGL(splat_mid_kernel<MODE>, dim3(tiles_x * mtiles_y * ta.split), dim3(256), smem_m, st, ta);
+        hipLaunchKernelGGL(splat_mid_kernel<MODE>, dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st, ta);
         TSP_HIP(hipGetLastError());
     }
     TSP_HIP(hipEventRecord(ctx->ev[5], st));
     if (hc.n_huge > 0) {
         ta.geom = (const float4 *)ws.huge_geom; ta.w = (const float *)ws.huge_w; ta.n_records = (long long)hc.n_huge;
-        // enough splits to give every CU several workgroups, but never more than there are batches
-        const long long batches = ((long long)hc.n_huge + 255) / 256;
-        const int htiles_x = (ctx->R + HTILE_W - 1) / HTILE_W, htiles = htiles_x * tiles_x;
-        int split = ctx->huge_split;
-        if (split <= 0) split = std::max(1, (ctx->cu_count * 16 + htiles - 1) / htiles);
-        split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
-        ta.split = split;
-        ta.tiles_x = htiles_x;
-        hipLaunchKernelGGL(splat_huge_kernel<MODE>, dim3(htiles * split), dim3(HT), smem_h, st, ta);
-        TSP_HIP(hipGetLastError());
+        if (MODE == TSP_MODE_RGB) rc = launch_huge<MODE, 3, 4>(ctx, ta, smem_h, (long long)hc.n_huge);
+        else if (second_channel) rc = launch_huge<MODE, 2, 4>(ctx, ta, smem_h, (long long)hc.n_huge);
+        else rc = launch_huge<MODE, 1, 4>(ctx, ta, smem_h, (long long)hc.n_huge);   // (PXH = 8 spills at 128 VGPRs)
+        if (rc) return rc;
     }
     TSP_HIP(hipEventRecord(ctx->ev[6], st));
     TSP_HIP(hipStreamSynchronize(st));
