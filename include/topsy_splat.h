@@ -163,7 +163,9 @@ int tsp_measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, doubl
 #define TSP_UNIQUE_ID_BYTES 128
 int tsp_comm_unique_id(char *id_out);
 int tsp_comm_init(tsp_context *ctx, int n_ranks, int rank, const char *id);
-/* Sum-reduce the render target to `root` (or to every rank when root < 0), float32, in place. */
+/* Sum-reduce the float32 render target to `root` (or to every rank when root < 0), in place.  Call it
+ * once after the frame's last tsp_render: a later tsp_render re-derives the local image from the
+ * rank's own float64 accumulator, i.e. the reduced copy is a presentation copy, not an accumulator. */
 int tsp_comm_reduce_image(tsp_context *ctx, int root, double *gpu_ms_out);
 int tsp_comm_destroy(tsp_context *ctx);
 

@@ -70,13 +70,13 @@ def test_weighted_matches_oracle(native, mips, cam, R, pipe):
     ctx.render(M, sf, mode=native.MODE_WEIGHTED, flags=flags)
     got = ctx.read_image()
     want, _ = oracle_render(pos, h, m, q, None, 0, M, sf, R, mips)
-    check_2ch(got, want, abs_terms_image(pos, h, m, q, M, sf, R, mips), rtol=3e-5 if pipe == "generic" else 1e-5)
+    check_2ch(got, want, abs_terms_image(pos, h, m, q, M, sf, R, mips), rtol=1e-5)
     # density-only (q = NULL): channel 1 must be exactly zero
     ctx.upload_quantity(None)
     ctx.render(M, sf, mode=native.MODE_WEIGHTED, flags=flags)
     got = ctx.read_image()
     assert (got[..., 1] == 0).all()
-    assert np.allclose(got[..., 0], want[..., 0], rtol=3e-5 if pipe == "generic" else 1e-5, atol=0)
+    assert np.allclose(got[..., 0], want[..., 0], rtol=1e-5, atol=0)
     ctx.close()
 
 
@@ -131,7 +131,7 @@ def test_ranges_and_accumulate(native, mips, pipe):
     got2 = ctx.read_image()
     want2, _ = oracle_render(pos, h, m, q, None, 0, M, sf, R, mips,
                              ranges=(np.array([0, 10, 700, 2500, 4990]), np.array([10, 300, 1, 1700, 10])))
-    check_2ch(got2, want2, at, rtol=2e-5)
+    check_2ch(got2, want2, at, rtol=1e-5)
     # empty selection: clear only
     ctx.render(M, sf, np.array([], dtype=np.int64), np.array([], dtype=np.int64), clear=True, flags=flags)
     assert (ctx.read_image() == 0).all()

@@ -1,0 +1,198 @@
+"""Full-size checks through size-independent properties (the oracle cannot run 1e8 particles in a
+test): pipeline == generic kernel, mass conservation, shard additivity (the multi-GPU contract),
+order invariance under the load-time reordering, block additivity, and the RCCL entry points."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def native():
+    from topsy_amd import _native
+    _native.load_library()
+    return _native
+
+
+def camera(scale):
+    M = np.eye(4, dtype=np.float32)
+    M[:3, :3] /= scale
+    M[2, :] = [0.0, 0.0, 0.5 / scale, 0.5]
+    return M, np.float32(1.0 / scale)
+
+
+def rel_close(a, b, rtol):
+    return (np.abs(a - b) <= rtol * np.maximum(np.abs(a), np.abs(b)) + 1e-30).all()
+
+
+def test_pipeline_equals_generic_and_oracle_1e6(native, mips):
+    """1e6-particle reference snapshot (BASELINE config 1 size), 512^2: the three-class pipeline, the
+    generic atomic kernel and the CPU oracle agree; every particle is accounted for exactly once."""
+    from oracle import oracle_c
+    n, R = 1000000, 512
+    M, sf = camera(200.0)
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.generate_synthetic(n, 0, n, 1337, 0.0, with_quantity=True)
+    d = ctx.download_particles(("x", "y", "z", "h", "mass", "q"))
+    ctx.set_option("count_fragments", 1)
+    ctx.render(M, sf)
+    a = ctx.read_image()
+    st = ctx.stats()
+    assert st["n_small"] + st["n_mid"] + st["n_huge"] + st["n_culled"] == n
+    want, nfrag = oracle_c.splat(d["x"], d["y"], d["z"], d["h"], d["mass"], d["q"], mode=0, M=M, sf=float(sf), R=R, mips=mips)
+    assert st["n_fragments"] == nfrag, "coverage decisions differ from the oracle"
+    assert rel_close(a[..., 0], want[..., 0], 1e-5)
+    scale, _ = oracle_c.splat(d["x"], d["y"], d["z"], d["h"], d["mass"], np.abs(d["q"]), mode=0, M=M, sf=float(sf), R=R, mips=mips)
+    assert (np.abs(a[..., 1] - want[..., 1]) <= 1e-5 * scale[..., 1] + 1e-30).all()
+    ctx.render(M, sf, flags=native.PIPE_GENERIC)
+    g = ctx.read_image()
+    assert ctx.stats()["n_fragments"] == nfrag
+    # (both paths accumulate the render target in float64)
+    assert rel_close(g[..., 0], want[..., 0], 1e-5)
+    # load-time reordering changes nothing but the summation order
+    ctx.reorder_spatial(32, 7)
+    ctx.render(M, sf)
+    b = ctx.read_image()
+    assert ctx.stats()["n_fragments"] == nfrag
+    assert rel_close(b[..., 0], want[..., 0], 1e-5)
+    ctx.close()
+
+
+@pytest.mark.parametrize("n,hcap_px", [(20000000, 0.0), (100000000, 8.0)])
+def test_mass_and_shard_additivity_at_scale(native, mips, n, hcap_px):
+    """sum over pixels * pixel area == visible mass; image(shard A) + image(shard B) == image(all)
+    (index-range shards, BASELINE config 4's contract), up to float32 summation noise."""
+    R, scale = 1024, 200.0
+    M, sf = camera(scale)
+    hcap = hcap_px * scale / (2.0 * R)
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.generate_synthetic(n, 0, n, 1337, hcap)
+    ctx.reorder_spatial(32, 1337)
+    ctx.render(M, sf)
+    full = ctx.read_image()[..., 0].astype(np.float64)
+    st = ctx.stats()
+    assert st["n_small"] + st["n_mid"] + st["n_huge"] + st["n_culled"] == n
+    mass = full.sum() * (2 * scale / R) ** 2
+    # particles outside the z-slab/viewport and sub-pixel footprints that miss every pixel centre are not
+    # drawn (reference semantics), the rest conserves mass: kernel mips are normalised to unit integral
+    assert 0.97 * n * 1e-8 < mass < 1.01 * n * 1e-8
+    # two index-range blocks of the SAME resident set, accumulated without clearing == one block
+    half = n // 2
+    ctx.render(M, sf, np.array([0]), np.array([half]), clear=True)
+    ctx.render(M, sf, np.array([half]), np.array([n - half]), clear=False)
+    two = ctx.read_image()[..., 0].astype(np.float64)
+    assert rel_close(two, full, 1e-5)
+    ctx.close()
+    # two separately generated shards (what two ranks hold) add up to the full image
+    parts = np.zeros((R, R), dtype=np.float64)
+    for first, count in ((0, half), (half, n - half)):
+        c = native.Context(R, 2)
+        c.set_kernel_mips(mips)
+        c.generate_synthetic(n, first, count, 1337, hcap)
+        c.reorder_spatial(32, 1337)
+        c.render(M, sf)
+        parts += c.read_image()[..., 0]
+        c.close()
+    assert rel_close(parts, full, 1e-5)
+
+
+def test_linearity_in_mass_and_rotation_symmetry(native, mips):
+    n, R = 2000000, 256
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.generate_synthetic(n, 0, n, 99, 0.0)
+    d = ctx.download_particles(("x", "y", "z", "h", "mass"))
+    M, sf = camera(60.0)
+    ctx.render(M, sf)
+    a = ctx.read_image()[..., 0].copy()
+    ctx.upload_particles(d["x"], d["y"], d["z"], d["h"], d["mass"] * np.float32(4.0))   # exact scaling
+    ctx.render(M, sf)
+    b = ctx.read_image()[..., 0]
+    assert rel_close(b, 4.0 * a, 1e-5)        # summation order differs between runs (atomics)
+    # 90 degree rotation about z == transpose + flip of the image (reference test_rotated_sph_output)
+    rot = np.array([[0.0, 1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    M2 = M.copy()
+    M2[:3, :3] = (np.diag([1, 1, 0.5]) @ rot / 60.0).astype(np.float32)
+    ctx.render(M2, sf)
+    c = ctx.read_image()[..., 0]
+    assert rel_close(b.T[:, ::-1], c, 1e-3)
+    ctx.close()
+
+
+def test_rgb_and_weighted_at_scale(native, mips):
+    """5e6-particle rgb (BASELINE config 5 mode) and weighted (config 2 mode): pipeline vs generic."""
+    n, R = 5000000, 1024
+    M, sf = camera(200.0)
+    ctx = native.Context(R, 4)
+    ctx.set_kernel_mips(mips)
+    ctx.generate_synthetic(n, 0, n, 5, 0.0, with_quantity=True, with_rgb=True)
+    ctx.reorder_spatial(32, 5)
+    ctx.set_option("count_fragments", 1)
+    for mode in (native.MODE_RGB, native.MODE_WEIGHTED, native.MODE_DEPTH):
+        ctx.render(M, sf, mode=mode)
+        a = ctx.read_image().astype(np.float64)
+        fa = ctx.stats()["n_fragments"]
+        ctx.render(M, sf, mode=mode, flags=native.PIPE_GENERIC)
+        g = ctx.read_image().astype(np.float64)
+        assert ctx.stats()["n_fragments"] == fa
+        assert rel_close(a[..., 0], g[..., 0], 1e-5)
+        if mode == native.MODE_RGB:
+            assert np.array_equal(a[..., 3], g[..., 3])          # fragment counter channel is exact
+            assert rel_close(a[..., 1:3], g[..., 1:3], 1e-5)
+        else:
+            tol = 1e-5 * np.abs(g[..., 1]).max()
+            assert np.abs(a[..., 1] - g[..., 1]).max() <= tol
+    ctx.close()
+
+
+def test_rccl_single_rank_reduce(native, mips):
+    """RCCL entry points on one GPU: communicator of size 1, in-place reduce leaves the image intact."""
+    ctx = native.Context(128, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.generate_synthetic(100000, 0, 100000, 3, 0.0)
+    M, sf = camera(100.0)
+    ctx.render(M, sf)
+    before = ctx.read_image()
+    assert ctx.comm_reduce_image(0) == 0.0            # no communicator: single GPU, nothing to do
+    uid = native.Context.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(1, 0, uid)
+    ms = ctx.comm_reduce_image(0)
+    assert ms >= 0.0
+    assert np.array_equal(ctx.read_image(), before)
+    ctx.comm_reduce_image(-1)                          # all-reduce form
+    assert np.array_equal(ctx.read_image(), before)
+    with pytest.raises(native.BackendError):
+        ctx.comm_init(1, 0, uid)                       # already initialised
+    ctx.close()
+
+
+def test_synthetic_generator_statistics(native, mips):
+    """The device generator restates TestDataLoader's distribution (loader.py:241-296)."""
+    n = 4000000
+    ctx = native.Context(64, 2)
+    ctx.generate_synthetic(n, 0, n, 1337, 0.0, with_quantity=True, with_rgb=True)
+    d = ctx.download_particles(("x", "y", "z", "h", "mass", "q", "r", "g", "b"))
+    pos = np.stack([d["x"], d["y"], d["z"]], axis=1).astype(np.float64)
+    # mixture moments: weights (.5,.4,.1), means (0,0,0),(0,0,0),(6,10,0), sigmas (20,20,20),(4,.2,4),(2,2,3)
+    np.testing.assert_allclose(pos.mean(axis=0), [0.6, 1.0, 0.0], atol=0.05)
+    var = 0.5 * np.array([400.0, 400, 400]) + 0.4 * np.array([16.0, 0.04, 16]) + 0.1 * (np.array([4.0, 4, 9]) + np.array([36.0, 100, 0])) \
+        - np.array([0.6, 1.0, 0.0]) ** 2
+    np.testing.assert_allclose(pos.var(axis=0), var, rtol=0.01)
+    # h-law: h = 2 / rho^0.333333 with the reference's (exponent without 1/2) density
+    W, MU, SD = [0.5, 0.4, 0.1], np.array([[0, 0, 0], [0, 0, 0], [6, 10, 0.0]]), np.array([[20, 20, 20], [4, 0.2, 4], [2, 2, 3.0]])
+    sel = slice(0, 50000)
+    den = sum(w * np.exp(-np.sum((pos[sel] - mu) ** 2 / sd ** 2, axis=1)) / ((2 * np.pi) ** 1.5 * np.prod(sd)) for w, mu, sd in zip(W, MU, SD)) * n
+    np.testing.assert_allclose(d["h"][sel], 2.0 / den ** 0.333333, rtol=2e-6)
+    assert (d["mass"] == np.float32(1e-8)).all()
+    np.testing.assert_allclose(d["q"][sel], np.sin(d["x"][sel]) * np.cos(d["y"][sel]) * np.cos(d["z"][sel]) * 1e-4, atol=2e-10)
+    np.testing.assert_allclose(d["r"][sel], np.abs(np.sin(d["x"][sel] / 10.0)), atol=1e-6)
+    # shards are reproducible: rows [a, b) of the full snapshot == a shard generated on its own
+    c2 = native.Context(64, 2)
+    c2.generate_synthetic(n, 1234567, 1000, 1337, 0.0)
+    s = c2.download_particles(("x", "h"))
+    assert np.array_equal(s["x"], d["x"][1234567:1235567]) and np.array_equal(s["h"], d["h"][1234567:1235567])
+    c2.close()
+    ctx.close()

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "tsp_internal.h"
@@ -33,6 +34,24 @@ int ensure_array(float **p, int64_t n) {
 static int upload_array(tsp_context *ctx, float **dst, const float *src, int64_t n) {
     if (!*dst) TSP_HIP(hipMalloc((void **)dst, (size_t)n * sizeof(float)));
     TSP_HIP(hipMemcpyAsync(*dst, src, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return TSP_OK;
+}
+
+__global__ void image_to_float_kernel(const double *__restrict__ src, float *__restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (float)src[i];
+}
+__global__ void image_to_double_kernel(const float *__restrict__ src, double *__restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (double)src[i];
+}
+
+int launch_image_convert(tsp_context *ctx, bool to_float) {
+    const int64_t n = (int64_t)ctx->R * ctx->R * ctx->C;
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 8);
+    if (to_float) hipLaunchKernelGGL(image_to_float_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->image64, ctx->image, n);
+    else hipLaunchKernelGGL(image_to_double_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->image, ctx->image64, n);
+    TSP_HIP(hipGetLastError());
     return TSP_OK;
 }
 
@@ -112,6 +131,8 @@ int tsp_create(int device_id, int resolution, int n_channels, tsp_context **out)
     const size_t npx = (size_t)resolution * resolution;
     TSP_HIP(hipMalloc((void **)&ctx->image, npx * n_channels * sizeof(float)));
     TSP_HIP(hipMemsetAsync(ctx->image, 0, npx * n_channels * sizeof(float), ctx->stream));
+    TSP_HIP(hipMalloc((void **)&ctx->image64, npx * n_channels * sizeof(double)));
+    TSP_HIP(hipMemsetAsync(ctx->image64, 0, npx * n_channels * sizeof(double), ctx->stream));
     TSP_HIP(hipMalloc((void **)&ctx->mips, MIP_TOTAL * sizeof(float)));
     TSP_HIP(hipMalloc((void **)&ctx->counters, sizeof(Counters)));
     TSP_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(Counters), ctx->stream));
@@ -126,7 +147,7 @@ void tsp_destroy(tsp_context *ctx) {
     (void)hipSetDevice(ctx->device);
     tsp_comm_destroy(ctx);
     free_particles(ctx);
-    void *ptrs[] = {ctx->image, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->scratch,
+    void *ptrs[] = {ctx->image, ctx->image64, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->scratch,
                     ctx->ws.mid_geom, ctx->ws.mid_w, ctx->ws.huge_geom, ctx->ws.huge_w, ctx->ws.seg_count, ctx->ws.seg_offset,
                     ctx->ws.seg_bbox, ctx->ws.range_prefix};
     for (void *p : ptrs)
@@ -276,7 +297,7 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
 
     TSP_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     if (clear)
-        TSP_HIP(hipMemsetAsync(ctx->image, 0, (size_t)ctx->R * ctx->R * ctx->C * sizeof(float), ctx->stream));
+        TSP_HIP(hipMemsetAsync(ctx->image64, 0, (size_t)ctx->R * ctx->R * ctx->C * sizeof(double), ctx->stream));
     TSP_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(Counters), ctx->stream));
     ctx->stats = tsp_stats{};
     ctx->stats.n_particles = total;
@@ -308,6 +329,7 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
         }
     }
     if (rc) return rc;
+    if ((rc = launch_image_convert(ctx, true))) return rc;     // round the float64 master image once
     TSP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     TSP_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
@@ -335,6 +357,9 @@ int tsp_write_image(tsp_context *ctx, const float *in) {
     TSP_REQUIRE(ctx && in, TSP_EINVAL, "NULL argument");
     TSP_HIP(hipSetDevice(ctx->device));
     TSP_HIP(hipMemcpy(ctx->image, in, (size_t)ctx->R * ctx->R * ctx->C * sizeof(float), hipMemcpyHostToDevice));
+    int rc = launch_image_convert(ctx, false);                 // keep the master copy consistent
+    if (rc) return rc;
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
     return TSP_OK;
 }
 

@@ -72,7 +72,8 @@ struct tsp_context {
     bool use_quantity = true;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
-    float *image = nullptr;           // R*R*C float32 render target
+    float *image = nullptr;           // R*R*C float32 render target (what read-back, colormap and reduce see)
+    double *image64 = nullptr;        // float64 master copy every kernel accumulates into (rounded once per render)
     float *mips = nullptr;            // 5440 floats
     bool have_mips = false;
     tsp::Particles p;
@@ -110,5 +111,6 @@ int generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int64_t
                        float h_cap, int with_quantity, int with_rgb);
 int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out);
 int measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, double *gbps_out);
+int launch_image_convert(tsp_context *ctx, bool to_float);   // image64 -> image (true) or image -> image64 (false)
 int ensure_array(float **p, int64_t n);
 }  // namespace tsp

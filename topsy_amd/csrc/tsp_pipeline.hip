@@ -43,7 +43,9 @@ template <int MODE> struct WinSize { static constexpr int value = (MODE == TSP_M
 
 enum { CLS_NONE = 0, CLS_SMALL = 1, CLS_MID = 2, CLS_HUGE = 3 };
 
-__device__ __forceinline__ void gatomic_add(float *addr, float v) {
+// the render target is accumulated in float64 (global_atomic_add_f64) and rounded to float32 once per
+// tsp_render call, so cross-workgroup summation adds no float32 noise however many flushes hit a pixel
+__device__ __forceinline__ void gatomic_add(double *addr, double v) {
     __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void latomic_add(double *addr, float v) {
@@ -77,7 +79,7 @@ struct StreamArgs {
     int chunks_per_block;
     Camera cam;
     const float *mips;
-    float *img;
+    double *img;
     float4 *mid_geom;  float *mid_w;   int64_t mid_capacity;
     float4 *huge_geom; float *huge_w;  int64_t huge_capacity;
     int *seg_count; long long *seg_offset; float4 *seg_bbox;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256, 4) void splat_stream_kernel(StreamArgs a) {
                 for (int c = 0; c < WC; ++c) {
                     const double v = win[c * WIN * WIN + o];
                     if (v != 0.0) {
-                        if (gx < R && gy < R) gatomic_add(a.img + ((size_t)gy * R + gx) * C + c, (float)v);
+                        if (gx < R && gy < R) gatomic_add(a.img + ((size_t)gy * R + gx) * C + c, v);
                         win[c * WIN * WIN + o] = 0.0;
                     }
                 }
@@ -287,8 +289,8 @@ __global__ __launch_bounds__(256, 4) void splat_stream_kernel(StreamArgs a) {
                             latomic_add(d, v0); latomic_add(d + WIN * WIN, v1);
                             latomic_add(d + 2 * WIN * WIN, v2); latomic_add(d + 3 * WIN * WIN, 1.0f);
                         } else {
-                            float *d = a.img + ((size_t)j * R + i) * C;
-                            gatomic_add(d, v0); gatomic_add(d + 1, v1); gatomic_add(d + 2, v2); gatomic_add(d + 3, 1.0f);
+                            double *d = a.img + ((size_t)j * R + i) * C;
+                            gatomic_add(d, v0); gatomic_add(d + 1, v1); gatomic_add(d + 2, v2); gatomic_add(d + 3, 1.0);
                         }
                     } else {
                         const float val = kv * w0[k];
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256, 4) void splat_stream_kernel(StreamArgs a) {
                             latomic_add(d, val);
                             if (WC > 1) latomic_add(d + WIN * WIN, v1);
                         } else {
-                            float *d = a.img + ((size_t)j * R + i) * C;
+                            double *d = a.img + ((size_t)j * R + i) * C;
                             gatomic_add(d, val);
                             if (WC > 1) gatomic_add(d + 1, v1);
                         }
@@ -357,7 +359,7 @@ struct TileArgs {
     const int *seg_count; const long long *seg_offset; const float4 *seg_bbox; int n_chunks;
     Camera cam;
     const float *mips;
-    float *img;
+    double *img;
     Counters *cnt;
     int tiles_x, split;
     int count_frag;
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const double v = tile[c * MTILE_H * MSTR + wy * MSTR + wx];
-                    if (v != 0.0) gatomic_add(a.img + ((size_t)gy * R + gx) * C + c, (float)v);
+                    if (v != 0.0) gatomic_add(a.img + ((size_t)gy * R + gx) * C + c, v);
                 }
             }
         }
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
                         for (int tx = 0; tx < 4; ++tx) {
                             const int p = ty * 4 + tx;
                             if (px0 + tx < R && py0 + ty < R) {
-                                float *d = a.img + ((size_t)(py0 + ty) * R + px0 + tx) * C;
+                                double *d = a.img + ((size_t)(py0 + ty) * R + px0 + tx) * C;
 #pragma unroll
                                 for (int c = 0; c < NACC; ++c) {
                                     if (acc[p][c] != 0.0f) gatomic_add(d + c, acc[p][c]);
@@ -684,7 +686,7 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
         for (int tx = 0; tx < 4; ++tx) {
             const int p = ty * 4 + tx, gx = px0 + tx, gy = py0 + ty;
             if (gx < R && gy < R) {
-                float *d = a.img + ((size_t)gy * R + gx) * C;
+                double *d = a.img + ((size_t)gy * R + gx) * C;
 #pragma unroll
                 for (int c = 0; c < NACC; ++c) {
                     const float v = (REG_TOTALS ? tot[p < NTOT ? p : 0][c] : 0.0f) + acc[p][c];
@@ -812,7 +814,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         const int max_blocks = ctx->cu_count * ctx->stream_blocks_per_cu;
         sa.chunks_per_block = std::max(1, (n_chunks + max_blocks - 1) / max_blocks);
         const int grid_s = (n_chunks + sa.chunks_per_block - 1) / sa.chunks_per_block;
-        sa.cam = cam; sa.mips = ctx->mips; sa.img = ctx->image;
+        sa.cam = cam; sa.mips = ctx->mips; sa.img = ctx->image64;
         sa.mid_geom = (float4 *)ws.mid_geom; sa.mid_w = (float *)ws.mid_w; sa.mid_capacity = ws.mid_capacity;
         sa.huge_geom = (float4 *)ws.huge_geom; sa.huge_w = (float *)ws.huge_w; sa.huge_capacity = ws.huge_capacity;
         sa.seg_count = ws.seg_count; sa.seg_offset = ws.seg_offset; sa.seg_bbox = ws.seg_bbox;
@@ -852,7 +854,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     }
     TileArgs ta;
     ta.seg_count = ws.seg_count; ta.seg_offset = ws.seg_offset; ta.seg_bbox = ws.seg_bbox; ta.n_chunks = n_chunks;
-    ta.cam = cam; ta.mips = ctx->mips; ta.img = ctx->image; ta.cnt = ctx->counters; ta.tiles_x = tiles_x;
+    ta.cam = cam; ta.mips = ctx->mips; ta.img = ctx->image64; ta.cnt = ctx->counters; ta.tiles_x = tiles_x;
     ta.count_frag = ctx->count_fragments ? 1 : 0;
     TSP_HIP(hipEventRecord(ctx->ev[4], st));
     if (hc.n_mid > 0) {

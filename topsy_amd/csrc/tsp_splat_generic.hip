@@ -1,5 +1,5 @@
 // tsp_splat_generic.hip -- the generic splat kernel: any particle order, any ranges, global
-// float atomics only.  It is the cross-check pipeline (TSP_PIPE_GENERIC) and the fallback the
+// atomics only (float32 terms added into the float64 master image).  It is the cross-check pipeline (TSP_PIPE_GENERIC) and the fallback the
 // three-class pipeline is validated against; arithmetic is the same canonical order (tsp_math.h).
 //
 // Reference semantics: vertex_weighting / vertex_depth / vertex_rgb + fragment_weighting /
@@ -12,8 +12,8 @@
 
 namespace tsp {
 
-__device__ __forceinline__ void atomic_add_f32(float *addr, float v) {
-    __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void atomic_add_f32(double *addr, float v) {   // float32 term into the float64 master image
+    __hip_atomic_fetch_add(addr, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ranges layout on device: [0,n) starts, [n,2n) lens, [2n,3n+1) prefix of lens
@@ -31,7 +31,7 @@ __device__ __forceinline__ int64_t work_to_particle(const int64_t *ranges, int n
 template <int MODE>
 __global__ __launch_bounds__(256) void splat_generic_kernel(Particles p, const int64_t *ranges, int n_ranges,
                                                             int64_t total, Camera cam, const float *mips_g,
-                                                            float *img, Counters *cnt, int count_frag) {
+                                                            double *img, Counters *cnt, int count_frag) {
     __shared__ float T[MIP_TOTAL];
     for (int i = threadIdx.x; i < MIP_TOTAL; i += 256) T[i] = mips_g[i];
     __syncthreads();
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void splat_generic_kernel(Particles p, const i
                 for (int i = ilo; i <= ihi; ++i) {
                     const float dx = ((float)i + 0.5f) - pr.pcx;
                     const float k = sample_kernel(T, pr, lvl, dx, dy);
-                    float *px = img + ((size_t)j * R + i) * C;
+                    double *px = img + ((size_t)j * R + i) * C;
                     if (MODE == TSP_MODE_RGB) {
                         atomic_add_f32(px + 0, k * w0);
                         atomic_add_f32(px + 1, k * w1);
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void splat_generic_kernel(Particles p, const i
                 const float dy = ((float)j + 0.5f) - q.pcy;
                 const float dx = ((float)i + 0.5f) - q.pcx;
                 const float k = sample_kernel(T, q, blvl, dx, dy);
-                float *px = img + ((size_t)j * R + i) * C;
+                double *px = img + ((size_t)j * R + i) * C;
                 if (MODE == TSP_MODE_RGB) {
                     atomic_add_f32(px + 0, k * a0);
                     atomic_add_f32(px + 1, k * a1);
@@ -144,15 +144,15 @@ int launch_generic(tsp_context *ctx, const Camera &cam, const int64_t *d_ranges,
     switch (mode) {
         case TSP_MODE_WEIGHTED:
             hipLaunchKernelGGL(splat_generic_kernel<TSP_MODE_WEIGHTED>, grid, block, 0, ctx->stream, parts, d_ranges,
-                               n_ranges, total, cam, ctx->mips, ctx->image, ctx->counters, cf);
+                               n_ranges, total, cam, ctx->mips, ctx->image64, ctx->counters, cf);
             break;
         case TSP_MODE_DEPTH:
             hipLaunchKernelGGL(splat_generic_kernel<TSP_MODE_DEPTH>, grid, block, 0, ctx->stream, parts, d_ranges,
-                               n_ranges, total, cam, ctx->mips, ctx->image, ctx->counters, cf);
+                               n_ranges, total, cam, ctx->mips, ctx->image64, ctx->counters, cf);
             break;
         case TSP_MODE_RGB:
             hipLaunchKernelGGL(splat_generic_kernel<TSP_MODE_RGB>, grid, block, 0, ctx->stream, parts, d_ranges,
-                               n_ranges, total, cam, ctx->mips, ctx->image, ctx->counters, cf);
+                               n_ranges, total, cam, ctx->mips, ctx->image64, ctx->counters, cf);
             break;
         default:
             set_error("bad mode %d", mode);
