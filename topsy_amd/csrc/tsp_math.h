@@ -63,20 +63,26 @@ __device__ __forceinline__ void cand(float pc, float half, int R, int &lo, int &
     hi = (int)b;     // hi < lo when the interval is empty (b can be < 0 -> negative int)
 }
 
-// Exact interval of covered pixels: refine the candidate interval with the canonical test.
+// Exact interval [lo, hi] of covered pixels along one axis, clipped to the image; lo > hi when empty.
+// Coverage is the canonical test |(i + 0.5) - pc| < half evaluated in float32; it holds on a contiguous
+// run of pixels whose ends lie within one pixel of the real-arithmetic bounds, so three candidate
+// tests per side decide it without loops or branches.
+__device__ __forceinline__ bool covers(float pc, float half, float i) {
+    return __builtin_fabsf((i + 0.5f) - pc) < half;
+}
 __device__ __forceinline__ void cover_range(float pc, float half, int R, int &lo, int &hi) {
-    cand(pc, half, R, lo, hi);
-    // candidate interval is at most 2 wider than the exact one on each side
-    for (int k = 0; k < 3 && lo <= hi; ++k) {
-        const float d = ((float)lo + 0.5f) - pc;
-        if (__builtin_fabsf(d) < half) break;
-        ++lo;
-    }
-    for (int k = 0; k < 3 && lo <= hi; ++k) {
-        const float d = ((float)hi + 0.5f) - pc;
-        if (__builtin_fabsf(d) < half) break;
-        --hi;
-    }
+    const float l0 = __builtin_floorf(pc - half - 0.5f) + 1.0f;    // first covered pixel in real arithmetic
+    const float h0 = __builtin_ceilf(pc + half - 0.5f) - 1.0f;     // last covered pixel in real arithmetic
+    float l = covers(pc, half, l0 - 1.0f) ? l0 - 1.0f : (covers(pc, half, l0) ? l0 : l0 + 1.0f);
+    float h = covers(pc, half, h0 + 1.0f) ? h0 + 1.0f : (covers(pc, half, h0) ? h0 : h0 - 1.0f);
+    // clip to [0, R-1] while still in float (the bounds may be far outside the int range)
+    l = l < 0.0f ? 0.0f : l;
+    const float rm = (float)(R - 1);
+    h = h > rm ? rm : h;
+    // an empty or fully clipped run must come out as lo > hi
+    const bool empty = !(l <= h);
+    lo = empty ? 1 : (int)l;
+    hi = empty ? 0 : (int)h;
 }
 
 __device__ __forceinline__ int level_for(float P) {   // -1 = bilinear on mip 0
