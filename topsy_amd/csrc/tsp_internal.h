@@ -76,6 +76,7 @@ struct tsp_context {
     double *image64 = nullptr;        // float64 master copy every kernel accumulates into (rounded once per render)
     float *mips = nullptr;            // 5440 floats
     bool have_mips = false;
+    bool lut_zero_outside_disc = false;   // every level-0 texel whose centre is >= 2h from the centre is exactly 0
     tsp::Particles p;
     tsp::Counters *counters = nullptr;
     tsp::Workspace ws;

@@ -363,6 +363,7 @@ struct TileArgs {
     Counters *cnt;
     int tiles_x, split;
     int count_frag;
+    float disc_k2;     // (0.5235)^2 when the LUT is zero outside the inscribed disc (exact corner culling), else 0
 };
 
 constexpr int MT = 512;              // threads per workgroup of kernel M (8 waves share tile + LUT)
@@ -531,6 +532,7 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
     }
     const int bx = tid & 31, by = tid >> 5;           // 4 x PXH pixel block owned by this lane
     const int px0 = tx0 + 4 * bx, py0 = ty0 + PXH * by;
+    const float sy0 = (float)(ty0 + 2 * PXH * wv), sy1 = sy0 + (float)(2 * PXH);     // this wave's pixel rows
     // pixel-centre coordinates; pixels outside the image get +inf so they are never covered
     float pxc[4], pyc[PXH];
 #pragma unroll
@@ -568,6 +570,10 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
             g = a.geom[ri];
             const float half = 0.5f * g.z;
             hit = (g.x + half > fx0) && (g.x - half < fx1) && (g.y + half > fy0) && (g.y - half < fy1);
+            // the kernel vanishes outside the disc inscribed in the footprint square: a tile wholly
+            // beyond radius 0.5221 P (all four stencil texels exactly 0) would only add +0.0
+            const float ddx = fmaxf(fmaxf(fx0 - g.x, g.x - fx1), 0.0f), ddy = fmaxf(fmaxf(fy0 - g.y, g.y - fy1), 0.0f);
+            hit = hit && !(a.disc_k2 > 0.0f && ddx * ddx + ddy * ddy >= a.disc_k2 * g.z * g.z);
         }
         const unsigned long long mask = __ballot(hit);
         const int before = __popcll(mask & ((1ull << lane) - 1ull));
@@ -589,8 +595,12 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
         // ---- every lane evaluates its pixels for each queued footprint ------------------------------
         for (int e = 0; e < nq; ++e) {
             const float4 r4 = qg[e];
-            const float4 wq = qw[e];
             const float pcx = r4.x, pcy = r4.y, half = r4.z, invP = r4.w;
+            {   // this wave's strip (128 x 2*PXH pixels): skip footprints whose square or disc misses it
+                const float sdx = fmaxf(fmaxf(fx0 - pcx, pcx - fx1), 0.0f), sdy = fmaxf(fmaxf(sy0 - pcy, pcy - sy1), 0.0f);
+                if (sdy >= half || (a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * (4.0f * half * half))) continue;
+            }
+            const float4 wq = qw[e];
             int col[4], row[PXH];
             float fxs[4], gxs[4], fys[PXH], gys[PXH];
             int ncov_x = 0, ncov_y = 0;
@@ -856,6 +866,8 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     ta.seg_count = ws.seg_count; ta.seg_offset = ws.seg_offset; ta.seg_bbox = ws.seg_bbox; ta.n_chunks = n_chunks;
     ta.cam = cam; ta.mips = ctx->mips; ta.img = ctx->image64; ta.cnt = ctx->counters; ta.tiles_x = tiles_x;
     ta.count_frag = ctx->count_fragments ? 1 : 0;
+    // corner culling is exact only for value channels (the rgb counter channel counts zero-valued fragments too)
+    ta.disc_k2 = (ctx->lut_zero_outside_disc && MODE != TSP_MODE_RGB && !ctx->count_fragments) ? 0.5235f * 0.5235f : 0.0f;
     TSP_HIP(hipEventRecord(ctx->ev[4], st));
     if (hc.n_mid > 0) {
         ta.geom = (const float4 *)ws.mid_geom; ta.w = (const float *)ws.mid_w; ta.n_records = (long long)hc.n_mid;
