@@ -165,13 +165,17 @@ int tsp_set_kernel_mips(tsp_context *ctx, const float *lut, int n0, int n_levels
     TSP_HIP(hipSetDevice(ctx->device));
     TSP_HIP(hipMemcpy(ctx->mips, lut, MIP_TOTAL * sizeof(float), hipMemcpyHostToDevice));
     ctx->have_mips = true;
-    // does the kernel vanish outside the inscribed disc?  texel (j, i) centre = -2 + (k + 0.5) / 16
+    // does the kernel vanish outside the inscribed disc, on every mip level?  level l has n = 64 >> l
+    // texels per side, texel (j, i) centre = -2 + (k + 0.5) * 4 / n
     bool zero = true;
-    for (int j = 0; j < 64 && zero; ++j)
-        for (int i = 0; i < 64; ++i) {
-            const double x = -2.0 + (i + 0.5) / 16.0, y = -2.0 + (j + 0.5) / 16.0;
-            if (x * x + y * y >= 4.0 && lut[j * 64 + i] != 0.0f) { zero = false; break; }
-        }
+    for (int l = 0, off = 0; l < 4 && zero; off += (64 >> l) * (64 >> l), ++l) {
+        const int n = 64 >> l;
+        for (int j = 0; j < n && zero; ++j)
+            for (int i = 0; i < n; ++i) {
+                const double x = -2.0 + (i + 0.5) * 4.0 / n, y = -2.0 + (j + 0.5) * 4.0 / n;
+                if (x * x + y * y >= 4.0 && lut[off + j * n + i] != 0.0f) { zero = false; break; }
+            }
+    }
     ctx->lut_zero_outside_disc = zero;
     return TSP_OK;
 }

@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256, 4) void splat_stream_kernel(StreamArgs a) {
                             gatomic_add(d, v0); gatomic_add(d + 1, v1); gatomic_add(d + 2, v2); gatomic_add(d + 3, 1.0);
                         }
                     } else {
+                        if (kv == 0.0f) continue;      // corner texels are exactly 0: adding +-0 changes nothing
                         const float val = kv * w0[k];
                         const float v1 = val * w1[k];
                         if (inw) {
