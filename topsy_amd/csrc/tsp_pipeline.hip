@@ -369,13 +369,14 @@ struct TileArgs {
 
 constexpr int MT = 512;              // threads per workgroup of kernel M (8 waves share tile + LUT)
 
-template <int MODE>
+// WC = channels accumulated in the LDS tile (1 for a density-only render, else the image's channel count)
+template <int MODE, int WC>
 __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
-    double *tile = smem_d;                                                   // [C][MTILE_H][MSTR]
-    float *T = reinterpret_cast<float *>(tile + C * MTILE_H * MSTR);         // mip pyramid, 5440 floats
+    double *tile = smem_d;                                                   // [WC][MTILE_H][MSTR]
+    float *T = reinterpret_cast<float *>(tile + WC * MTILE_H * MSTR);        // mip pyramid, 5440 floats
     __shared__ long long s_seg_off[MT];
     __shared__ int s_seg_cnt[MT];
     __shared__ int s_wcnt[MT / 64];
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
     const int tx0 = (tile_id % a.tiles_x) * TILE, ty0 = (tile_id / a.tiles_x) * MTILE_H;
     const float fx0 = (float)tx0, fy0 = (float)ty0, fx1 = (float)(tx0 + TILE), fy1 = (float)(ty0 + MTILE_H);
     for (int i = tid; i < MIP_TOTAL; i += MT) T[i] = a.mips[i];
-    for (int i = tid; i < C * MTILE_H * MSTR; i += MT) tile[i] = 0.0;
+    for (int i = tid; i < WC * MTILE_H * MSTR; i += MT) tile[i] = 0.0;
     __syncthreads();
     const int lx = lane & 7, ly = lane >> 3;
     unsigned long long n_frag = 0;
@@ -470,7 +471,8 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                                     latomic_add(d + 2 * MTILE_H * MSTR, kv * w2); latomic_add(d + 3 * MTILE_H * MSTR, 1.0f);
                                 } else {
                                     const float val = kv * w0;
-                                    latomic_add(d, val); latomic_add(d + MTILE_H * MSTR, val * w1);
+                                    latomic_add(d, val);
+                                    if (WC > 1) latomic_add(d + MTILE_H * MSTR, val * w1);
                                 }
                             }
                         }
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
             const int gx = tx0 + wx, gy = ty0 + wy;
             if (gx < R && gy < R) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
+                for (int c = 0; c < WC; ++c) {
                     const double v = tile[c * MTILE_H * MSTR + wy * MSTR + wx];
                     if (v != 0.0) gatomic_add(a.img + ((size_t)gy * R + gx) * C + c, v);
                 }
@@ -805,14 +807,15 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     const bool second_channel = (MODE == TSP_MODE_DEPTH) || (MODE == TSP_MODE_RGB) || (ctx->p.q != nullptr && ctx->use_quantity);
     const int WCr = (MODE == TSP_MODE_RGB) ? 4 : (second_channel ? 2 : 1);
     const size_t smem_s = (size_t)WCr * WIN * WIN * sizeof(double) + 64 * sizeof(float);
-    const size_t smem_m = (size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float);
+    const size_t smem_m = (size_t)WCr * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float);
     const int mtiles_y = (ctx->R + MTILE_H - 1) / MTILE_H;
     const size_t smem_h = (size_t)(64 * 64 + 512) * sizeof(float4);
     static bool attr_set[3] = {false, false, false};
     if (!attr_set[MODE]) {
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WIN * WIN * sizeof(double) + 256)));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WIN * WIN * sizeof(double) + 256)));
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_m));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
         attr_set[MODE] = true;
     }
 
@@ -873,7 +876,8 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     if (hc.n_mid > 0) {
         ta.geom = (const float4 *)ws.mid_geom; ta.w = (const float *)ws.mid_w; ta.n_records = (long long)hc.n_mid;
         ta.split = ctx->mid_split;
-        hipLaunchKernelGGL(splat_mid_kernel<MODE>, dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st, ta);
+        if (WCr == 1) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1>), dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st, ta);
+        else hipLaunchKernelGGL((splat_mid_kernel<MODE, C>), dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st, ta);
         TSP_HIP(hipGetLastError());
     }
     TSP_HIP(hipEventRecord(ctx->ev[5], st));
