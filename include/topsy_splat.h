@@ -139,6 +139,20 @@ int tsp_colormap_scalar_host(tsp_context *ctx, const float *img, int H, int W, i
 int tsp_colormap_rgb_host(tsp_context *ctx, const float *img, int H, int W, int C, float vmin,
                           float vmax, float gamma, uint8_t *out_rgba8, float *out_rgba_f32);
 
+/* On-device autorange support (replaces the image read-back + host
+ * np.percentile of Colormap.autorange_vmin_vmax / _autorange_using_values, reference
+ * src/topsy/colormap/implementation.py:381-425, and RGBColormap.autorange_vmin_vmax :512-531).
+ * tsp_content_sort computes the logical content of the render target scaled by `scale` in the same
+ * float32 arithmetic numpy uses on the host (kind 0: ch0*scale; 1: (ch1*scale)/(ch0*scale);
+ * 2: the three colour channels of an rgb image, flattened; 3: every channel of the image, flattened --
+ * what the reference's RGBColormap.autorange_vmin_vmax sees, since it ravel()s the raw 4-channel image
+ * including the fragment-count channel), sorts the FINITE values on the device
+ * and reports how many there are and how many of them are <= 0.  tsp_content_values then returns
+ * the values at the given ranks of that ascending order (the host needs only a handful: min, max,
+ * and the neighbours of each percentile's virtual index). */
+int tsp_content_sort(tsp_context *ctx, int kind, float scale, int64_t *n_finite, int64_t *n_nonpositive);
+int tsp_content_values(tsp_context *ctx, const int64_t *ranks, int n_ranks, float *out);
+
 /* Counters of the last tsp_render call (measurement aid). */
 typedef struct {
     int64_t n_particles;   /* particles visited (sum of range lengths) */

@@ -181,3 +181,25 @@ def test_colormap_vs_matplotlib(mode, log_scale):  # reference tests/test_colorm
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+@pytest.mark.parametrize("mode,quantity", [("univariate", None), ("univariate", "test-quantity"), ("rgb", None), ("rgb-hdr", None)])
+def test_device_autorange_equals_host_autorange(mode, quantity):
+    """autorange from device-side order statistics == autorange(get_image()) on the host."""
+    v = topsy_amd.test(20000, render_resolution=256, render_mode=mode)
+    v.scale = 40.0
+    if quantity:
+        v.quantity_name = quantity
+    v.render_sph(DrawReason.EXPORT)
+    for S in (1.0, 3.7):
+        v._sph.last_render_mass_scale = S
+        v.colormap.update_parameters({"vmin": 0.0, "vmax": 1.0})
+        v.colormap.autorange(v._sph.get_image())
+        host = v.colormap.get_parameters()
+        v.colormap.update_parameters({"vmin": 0.0, "vmax": 1.0})
+        v.colormap.autorange_on_device(S)
+        dev = v.colormap.get_parameters()
+        for k in ("vmin", "vmax", "log", "ui_range_linear", "ui_range_log"):
+            if k in host:
+                assert np.array_equal(np.asarray(host[k]), np.asarray(dev[k])), (k, host[k], dev[k])
+    v.close()

@@ -67,6 +67,8 @@ SIGNATURES = {
                                                 ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _u8p]),
     "tsp_colormap_rgb_host": (ctypes.c_int, [_ctx, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                              ctypes.c_float, ctypes.c_float, _u8p, _fp]),
+    "tsp_content_sort": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_float, _i64p, _i64p]),
+    "tsp_content_values": (ctypes.c_int, [_ctx, _i64p, ctypes.c_int, _fp]),
     "tsp_get_stats": (ctypes.c_int, [_ctx, ctypes.POINTER(Stats)]),
     "tsp_set_option": (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.c_int64]),
     "tsp_measure_read_bandwidth": (ctypes.c_int, [_ctx, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
@@ -228,6 +230,18 @@ class Context:
         self.set_option("active_channels", img.shape[2])
         self.active_channels = img.shape[2]
         _check(self._lib.tsp_write_image(self._h, _ptr(img)))
+
+    def content_sort(self, kind, scale=1.0):
+        """Sort the finite content values on the device; returns (n_finite, n_nonpositive)."""
+        nf, nnp = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(self._lib.tsp_content_sort(self._h, int(kind), float(np.float32(scale)), ctypes.byref(nf), ctypes.byref(nnp)))
+        return nf.value, nnp.value
+
+    def content_values(self, ranks):
+        r = np.ascontiguousarray(ranks, dtype=np.int64)
+        out = np.empty(len(r), dtype=np.float32)
+        _check(self._lib.tsp_content_values(self._h, r.ctypes.data_as(_i64p), len(r), _ptr(out)))
+        return out
 
     def stats(self):
         s = Stats()

@@ -60,6 +60,11 @@ class ColormapHolder:
         self._check_valid()
         self._impl.autorange_vmin_vmax(sph_render_output)
 
+    def autorange_on_device(self, mass_scaling=1.0):
+        """Same result as autorange(sph.get_image()) computed from device-side order statistics."""
+        self._check_valid()
+        self._impl.autorange_on_device(mass_scaling)
+
     def encode_render_pass(self, command_encoder, target_texture_view):
         self._check_valid()
         return self._impl.encode_render_pass(command_encoder, target_texture_view)

@@ -17,6 +17,34 @@ _UINT8_FORMATS = ("rgba8unorm", "bgra8unorm")
 _FLOAT_FORMATS = ("rgba16float", "rgba32float")
 
 
+def percentile_from_order_statistics(fetch, first, n, q, transform=None):
+    """np.percentile(sample, q) (method 'linear') where the float32 `sample` is known only through its
+    order statistics: fetch(ranks) returns the values at the given ascending ranks, the sample is the n
+    values starting at rank `first`, optionally passed through the monotone `transform` (np.log10).
+
+    Follows numpy's own arithmetic step by step (numpy/lib/_function_base_impl.py): the divisor 100 takes
+    the data dtype, so a Python-float q interpolates in float32 and an array q in float64; virtual index
+    (n-1)*q; _lerp with its t >= 0.5 branch.  The device autorange therefore equals the host one bit for
+    bit (tests/test_host_logic.py, tests/test_gpu_visualizer.py)."""
+    scalar = np.ndim(q) == 0
+    quantiles = np.true_divide(q, np.float32(100))          # Python float -> float32, float64 array stays
+    virtual = np.asanyarray((n - 1) * quantiles)
+    prev_f = np.floor(virtual)
+    prev = np.atleast_1d(prev_f).astype(np.intp)
+    nxt = np.minimum(prev + 1, n - 1)
+    gamma = np.asanyarray(virtual - prev_f)
+    vals = np.asarray(fetch(np.concatenate([first + prev, first + nxt])), dtype=np.float32)
+    if transform is not None:
+        vals = transform(vals)
+    a, b = vals[:len(prev)], vals[len(prev):]
+    if scalar:
+        a, b = a[0], b[0]
+    diff = np.subtract(b, a)
+    out = np.asanyarray(np.add(a, diff * gamma))
+    np.subtract(b, diff * (1 - gamma), out=out, where=gamma >= 0.5, casting="unsafe", dtype=type(out.dtype))
+    return out[()] if scalar else out
+
+
 def _lut_from_matplotlib(name, num_points):
     import matplotlib
     return matplotlib.colormaps[name](np.linspace(0.001, 0.999, num_points)).astype(np.float32)
@@ -128,6 +156,41 @@ class Colormap(ColormapBase):
             self._params["vmin"], self._params["vmax"] = 0.0, 1.0
         self.update_parameters({"ui_range_linear": (lo, hi), "ui_range_log": (lo_log, hi_log), "log": use_log})
         logger.info(f"Autoscale: log_scale={self._params['log']}, vmin={self._params['vmin']}, vmax={self._params['vmax']}")
+
+    def autorange_on_device(self, mass_scale=1.0):
+        """autorange_vmin_vmax(get_image()) without reading the image back: the device sorts the finite
+        content values (tsp_content_sort) and the host needs ~8 of them."""
+        ctx = self._input_texture.context
+        kind = 1 if self._params["weighted_average"] else 0
+        n_fin, n_nonpos = ctx.content_sort(kind, mass_scale)
+        fetch = ctx.content_values
+        n_pos = n_fin - n_nonpos
+        with np.errstate(divide="ignore", invalid="ignore"):
+            if n_fin:
+                lo, hi = fetch([0, n_fin - 1])
+                any_negative = bool(lo < 0)
+            else:
+                lo = hi = np.nan
+                any_negative = False
+            if n_pos:
+                lo_log, hi_log = np.log10(fetch([n_nonpos, n_fin - 1]))
+            else:
+                lo_log = hi_log = np.nan
+        if hi_log == lo_log:
+            hi_log, lo_log = hi_log + 1.0, lo_log - 1.0
+        if hi == lo:
+            hi, lo = hi + 1.0, lo - 1.0
+        use_log = not any_negative
+        first, n, tf = (n_nonpos, n_pos, np.log10) if use_log else (0, n_fin, None)
+        if n > 200:
+            self._params["vmin"], self._params["vmax"] = percentile_from_order_statistics(fetch, first, n, self.percentile_scaling, tf)
+        elif n > 2:
+            ends = fetch([first, first + n - 1])
+            self._params["vmin"], self._params["vmax"] = (tf(ends) if tf else ends)
+        else:
+            logger.warning("Problem setting vmin/vmax, perhaps there are no particles or something is wrong with them?")
+            self._params["vmin"], self._params["vmax"] = 0.0, 1.0
+        self.update_parameters({"ui_range_linear": (lo, hi), "ui_range_log": (lo_log, hi_log), "log": use_log})
 
     # -- shader parameters (reference :427-453) -------------------------------------------------
     def _update_parameter_buffer(self, width, height, mass_scale):
@@ -260,6 +323,21 @@ class RGBColormap(Colormap):
 
     def sph_raw_output_to_content(self, numpy_image):
         return numpy_image[..., :3]
+
+    def autorange_on_device(self, mass_scale=1.0):
+        ctx = self._input_texture.context
+        # kind 3 = every channel of the raw image: the reference passes sph.get_image() (R,R,4) and ravel()s
+        # it, so the fragment-count channel takes part in the percentile (implementation.py:512-516)
+        n_fin, n_nonpos = ctx.content_sort(3, mass_scale)
+        n = n_fin - n_nonpos                     # log10 is finite exactly for the positive finite values
+        if n > 200:
+            self._params["vmax"] = percentile_from_order_statistics(ctx.content_values, n_nonpos, n, self.max_percentile, np.log10)
+        elif n > 2:
+            self._params["vmax"] = np.log10(ctx.content_values([n_fin - 1]))[0]
+        else:
+            logger.warning("Problem setting vmin/vmax, perhaps there are no particles or something is wrong with them?")
+            self._params["vmax"] = 1.0
+        self._params["vmin"] = self._params["vmax"] - self.dynamic_range
 
     def _run(self, fn):
         p = self._shader_params

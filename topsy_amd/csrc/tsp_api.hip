@@ -149,7 +149,7 @@ void tsp_destroy(tsp_context *ctx) {
     free_particles(ctx);
     void *ptrs[] = {ctx->image, ctx->image64, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->scratch,
                     ctx->ws.mid_geom, ctx->ws.mid_w, ctx->ws.huge_geom, ctx->ws.huge_w, ctx->ws.seg_count, ctx->ws.seg_offset,
-                    ctx->ws.seg_bbox, ctx->ws.range_prefix};
+                    ctx->ws.seg_bbox, ctx->ws.range_prefix, ctx->sort_keys, ctx->sort_keys_alt, ctx->sort_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &e : ctx->ev)
@@ -465,6 +465,29 @@ int tsp_colormap_rgb_host(tsp_context *ctx, const float *img, int H, int W, int 
     if (out_rgba8) TSP_HIP(hipMemcpyAsync(out_rgba8, d_o8, (size_t)npix * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_rgba_f32) TSP_HIP(hipMemcpyAsync(out_rgba_f32, d_of, of, hipMemcpyDeviceToHost, ctx->stream));
     TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
+int tsp_content_sort(tsp_context *ctx, int kind, float scale, int64_t *n_finite, int64_t *n_nonpositive) {
+    TSP_REQUIRE(ctx && n_finite && n_nonpositive, TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(kind >= 0 && kind <= 3, TSP_EINVAL, "bad content kind %d", kind);
+    TSP_REQUIRE(kind != 2 || ctx->C == 4, TSP_EINVAL, "rgb content needs a 4-channel image");
+    TSP_HIP(hipSetDevice(ctx->device));
+    return content_sort(ctx, kind, scale, n_finite, n_nonpositive);
+}
+
+int tsp_content_values(tsp_context *ctx, const int64_t *ranks, int n_ranks, float *out) {
+    TSP_REQUIRE(ctx && ranks && out && n_ranks >= 0, TSP_EINVAL, "bad argument");
+    TSP_REQUIRE(ctx->sort_keys_alt, TSP_ESTATE, "tsp_content_sort has not been called");
+    TSP_HIP(hipSetDevice(ctx->device));
+    for (int i = 0; i < n_ranks; ++i) {
+        TSP_REQUIRE(ranks[i] >= 0 && ranks[i] < ctx->sorted_count, TSP_EINVAL, "rank %lld outside [0, %lld)",
+                    (long long)ranks[i], (long long)ctx->sorted_count);
+        uint32_t key;
+        TSP_HIP(hipMemcpy(&key, ctx->sort_keys_alt + ranks[i], 4, hipMemcpyDeviceToHost));
+        const uint32_t bits = (key & 0x80000000u) ? (key & 0x7fffffffu) : ~key;   // inverse of the monotone map
+        memcpy(&out[i], &bits, 4);
+    }
     return TSP_OK;
 }
 

@@ -6,6 +6,7 @@
 //   * the float4 read-sum microbenchmark that measures the HBM streaming-read peak.
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <vector>
 
 #include "tsp_internal.h"
@@ -251,6 +252,71 @@ int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm
         TSP_HIP(hipMemcpy(hp.data(), p.perm, (size_t)n * 4, hipMemcpyDeviceToHost));
         for (int64_t i = 0; i < n; ++i) perm_out[i] = (int64_t)hp[(size_t)i];
     }
+    return TSP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// on-device autorange: sort the finite content values of the render target
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void content_key_kernel(const float *__restrict__ img, int64_t npix, int C, int kind,
+                                                          float scale, uint32_t *__restrict__ keys,
+                                                          unsigned long long *counts /* [finite, nonpositive] */) {
+    unsigned long long nf = 0, nnp = 0;
+    const int per_px = (kind == 2) ? 3 : (kind == 3 ? C : 1);
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < npix * per_px; t += (int64_t)gridDim.x * 256) {
+        float v;
+        if (kind == 2) {
+            v = img[(t / 3) * C + (t % 3)] * scale;
+        } else if (kind == 3) {
+            v = img[t] * scale;                                 // every channel, as vals.ravel() of the raw image
+        } else {
+            const float a = img[t * C] * scale;                 // get_image(): raw * mass_scale (float32)
+            v = (kind == 1) ? (img[t * C + 1] * scale) / a : a; // weighted content: ch1 / ch0
+        }
+        const bool fin = (v == v) && (__builtin_fabsf(v) != __builtin_inff());
+        keys[t] = fin ? ordered_u32(v) : 0xFFFFFFFFu;
+        nf += fin;
+        nnp += fin && (v <= 0.0f);
+    }
+    for (int o = 32; o; o >>= 1) {
+        nf += __shfl_xor((long long)nf, o);
+        nnp += __shfl_xor((long long)nnp, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (nf) atomicAdd(&counts[0], nf);
+        if (nnp) atomicAdd(&counts[1], nnp);
+    }
+}
+
+int content_sort(tsp_context *ctx, int kind, float scale, int64_t *n_finite, int64_t *n_nonpositive) {
+    const int64_t npix = (int64_t)ctx->R * ctx->R;
+    const int64_t n = npix * (kind == 2 ? 3 : (kind == 3 ? ctx->C : 1));
+    hipStream_t st = ctx->stream;
+    if (ctx->sort_capacity < n) {
+        if (ctx->sort_keys) TSP_HIP(hipFree(ctx->sort_keys));
+        if (ctx->sort_keys_alt) TSP_HIP(hipFree(ctx->sort_keys_alt));
+        if (ctx->sort_tmp) TSP_HIP(hipFree(ctx->sort_tmp));
+        ctx->sort_tmp = nullptr;
+        TSP_HIP(hipMalloc((void **)&ctx->sort_keys, (size_t)n * 4));
+        TSP_HIP(hipMalloc((void **)&ctx->sort_keys_alt, (size_t)n * 4));
+        ctx->sort_capacity = n;
+        ctx->sort_tmp_bytes = 0;
+        TSP_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, ctx->sort_tmp_bytes, ctx->sort_keys, ctx->sort_keys_alt, n, 0, 32, st));
+        TSP_HIP(hipMalloc(&ctx->sort_tmp, ctx->sort_tmp_bytes ? ctx->sort_tmp_bytes : 16));
+    }
+    unsigned long long *counts = reinterpret_cast<unsigned long long *>(ctx->counters);   // scratch: reuse the counter block
+    TSP_HIP(hipMemsetAsync(counts, 0, 2 * sizeof(unsigned long long), st));
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 8);
+    hipLaunchKernelGGL(content_key_kernel, dim3(grid), dim3(256), 0, st, ctx->image, npix, ctx->C, kind, scale, ctx->sort_keys, counts);
+    TSP_HIP(hipGetLastError());
+    size_t tmp_bytes = ctx->sort_tmp_bytes;
+    TSP_HIP(hipcub::DeviceRadixSort::SortKeys(ctx->sort_tmp, tmp_bytes, ctx->sort_keys, ctx->sort_keys_alt, n, 0, 32, st));
+    unsigned long long hc[2];
+    TSP_HIP(hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, st));
+    TSP_HIP(hipStreamSynchronize(st));
+    ctx->sorted_count = (int64_t)hc[0];
+    *n_finite = (int64_t)hc[0];
+    *n_nonpositive = (int64_t)hc[1];
     return TSP_OK;
 }
 

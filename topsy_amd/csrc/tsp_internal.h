@@ -86,6 +86,10 @@ struct tsp_context {
     int lut_capacity = 0;
     void *scratch = nullptr;          // host-image colormap staging
     size_t scratch_bytes = 0;
+    uint32_t *sort_keys = nullptr, *sort_keys_alt = nullptr;   // content order statistics (autorange)
+    void *sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    int64_t sort_capacity = 0, sorted_count = 0;
     tsp_stats stats = {};
     bool count_fragments = false;
     // pipeline tuning (tsp_set_option)
@@ -112,6 +116,7 @@ int generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int64_t
                        float h_cap, int with_quantity, int with_rgb);
 int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out);
 int measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, double *gbps_out);
-int launch_image_convert(tsp_context *ctx, bool to_float);   // image64 -> image (true) or image -> image64 (false)
+int launch_image_convert(tsp_context *ctx, bool to_float);
+int content_sort(tsp_context *ctx, int kind, float scale, int64_t *n_finite, int64_t *n_nonpositive);   // image64 -> image (true) or image -> image64 (false)
 int ensure_array(float **p, int64_t n);
 }  // namespace tsp

@@ -116,10 +116,14 @@ class SPH:
     def get_image(self):
         return self._get_image_unscaled() * self.last_render_mass_scale
 
-    def _get_image_unscaled(self):
+    def ensure_rendered(self):
+        """Trigger an EXPORT-quality render unless this renderer's image is resident (reference sph.py:127-131)."""
         if not self.has_rendered or getattr(self._visualizer.particle_buffers, "last_renderer", None) is not self:
             logger.info("Export-quality render has been triggered, because no valid render is resident.")
             self.render(DrawReason.EXPORT)
+
+    def _get_image_unscaled(self):
+        self.ensure_rendered()
         return self._context.read_image()
 
     def get_output_texture(self):

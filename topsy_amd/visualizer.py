@@ -93,7 +93,7 @@ class VisualizerBase:
         params = self._colormap.get_parameters()
         if changed_type or params["vmin"] is None or params["vmax"] is None:
             logger.info("Autorange colormap parameters")
-            self._colormap.autorange(self._sph.get_image())
+            self._autorange()
 
     def _update_render_mode(self, new_render_mode, revert_on_failure=True):
         self._validate_render_mode(new_render_mode)
@@ -195,8 +195,13 @@ class VisualizerBase:
     def averaging(self):
         return self.quantity_name is not None
 
+    def _autorange(self):
+        """colormap.autorange(sph.get_image()) (reference visualizer.py:313,336) without the read-back."""
+        self._sph.ensure_rendered()
+        self._colormap.autorange_on_device(self._sph.last_render_mass_scale)
+
     def colormap_autorange(self):
-        self._colormap.autorange(self._sph.get_image())
+        self._autorange()
         self.invalidate(DrawReason.PRESENTATION_CHANGE)
 
     # -- drawing (reference visualizer.py:386-405) ---------------------------------------------
