@@ -545,7 +545,7 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
     // Accumulation is two-level so the float32 error stays ~sqrt(run length) * 2^-24 instead of
     // sqrt(n): short runs in `acc`, folded into `tot` (PXH == 4) or, when the registers are needed
     // for the taller pixel block, straight into the render target (PXH == 8).
-    constexpr bool REG_TOTALS = (PXH == 4);
+    constexpr bool REG_TOTALS = (PXH == 4) && (NACC < 3);     // rgb: 3 accumulators + counter leave no room for totals
     constexpr int NTOT = REG_TOTALS ? NPX : 1;
     constexpr int FOLD_EVERY = REG_TOTALS ? 64 : 1024;
     float acc[NPX][NACC], tot[NTOT][NACC];
@@ -606,6 +606,7 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
             const float4 wq = qw[e];
             int col[4], row[PXH];
             float fxs[4], gxs[4], fys[PXH], gys[PXH];
+            float cvx[4], cvy[PXH];               // rgb only: coverage flags for the fragment counter
             int ncov_x = 0, ncov_y = 0;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -621,6 +622,7 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
                 col[t] = (int)f0;
                 fxs[t] = fr;
                 gxs[t] = cv - fr;
+                if (MODE == TSP_MODE_RGB) cvx[t] = cv;
                 ncov_x += (cv != 0.0f);
             }
 #pragma unroll
@@ -634,6 +636,7 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
                 row[t] = ((int)f0) << 6;
                 fys[t] = fr;
                 gys[t] = cv - fr;
+                if (MODE == TSP_MODE_RGB) cvy[t] = cv;
                 ncov_y += (cv != 0.0f);
             }
 #pragma unroll
@@ -660,7 +663,7 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
                 for (int ty = 0; ty < PXH; ++ty)
 #pragma unroll
                     for (int tx = 0; tx < 4; ++tx)
-                        cnt_acc[ty * 4 + tx] += (gys[ty] + fys[ty]) * (gxs[tx] + fxs[tx]);   // 1 iff covered
+                        cnt_acc[ty * 4 + tx] = __builtin_fmaf(cvy[ty], cvx[tx], cnt_acc[ty * 4 + tx]);   // += 1 iff covered
             }
             if (a.count_frag) n_frag += (unsigned long long)(ncov_x * ncov_y);
             // fold the short-run accumulators into the totals every 64 footprints: bounds the
