@@ -131,6 +131,17 @@ int tsp_colormap_scalar(tsp_context *ctx, const float *lut_rgba, int n_lut, floa
 int tsp_colormap_rgb(tsp_context *ctx, float vmin, float vmax, float gamma, uint8_t *out_rgba8,
                      float *out_rgba_f32);
 
+/* Bivariate map: colormap.wgsl fragment_main BIVARIATE branch (:91-111) with
+ * the 2-D LUT of BivariateColormap._generate_mapping_rgba_f32 (implementation.py:585-605), n x n x RGBA
+ * float32, first axis = normalised (weighted) value, second axis = normalised log10 density.  The LUT
+ * (16 MB at n = 1000) is uploaded once with tsp_colormap_set_lut2d and stays resident. */
+int tsp_colormap_set_lut2d(tsp_context *ctx, const float *lut_rgba, int n);
+int tsp_colormap_bivariate(tsp_context *ctx, float vmin, float vmax, float density_vmin, float density_vmax,
+                           int log_scale, int weighted, uint8_t *out_rgba);
+int tsp_colormap_bivariate_host(tsp_context *ctx, const float *img, int H, int W, int C, float vmin, float vmax,
+                                float density_vmin, float density_vmax, int log_scale, int weighted,
+                                uint8_t *out_rgba);
+
 /* Same maps applied to an arbitrary host image (H x W x C float32), the entry
  * Colormap.sph_raw_output_to_image drives (implementation.py:132-201). */
 int tsp_colormap_scalar_host(tsp_context *ctx, const float *img, int H, int W, int C,

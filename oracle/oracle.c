@@ -311,6 +311,33 @@ void orc_colormap_rgb(const float *img, long npix, int C, float vmin, float vmax
     }
 }
 
+/* fragment_main, BIVARIATE branch (colormap.wgsl:91-111).  lut2d: n x n x RGBA, [y (value)][x (density)]. */
+void orc_colormap_bivariate(const float *img, long npix, int C, const float *lut2d, int n, float vmin, float vmax,
+                            float dvmin, float dvmax, int log_scale, int weighted, uint8_t *out) {
+    const float range = vmax - vmin, drange = dvmax - dvmin;
+#pragma omp parallel for schedule(static)
+    for (long p = 0; p < npix; ++p) {
+        float x = (orc_log10f(img[p * C]) - dvmin) / drange;
+        float y = weighted ? img[p * C + 1] / img[p * C] : img[p * C];
+        if (log_scale) y = orc_log10f(y);
+        y = (y - vmin) / range;
+        if (x != x || x < 0.0f) x = 0.0f;
+        if (x > 1.0f) x = 1.0f;
+        if (y != y || y < 0.0f) y = 0.0f;
+        if (y > 1.0f) y = 1.0f;
+        float cx = x * (float)n - 0.5f, cy = y * (float)n - 0.5f;
+        float x0 = floorf(cx), y0 = floorf(cy);
+        float fx = cx - x0, fy = cy - y0, gx = 1.0f - fx, gy = 1.0f - fy;
+        int i0 = clampi((int)x0, 0, n - 1), i1 = clampi((int)x0 + 1, 0, n - 1);
+        int j0 = clampi((int)y0, 0, n - 1), j1 = clampi((int)y0 + 1, 0, n - 1);
+        for (int k = 0; k < 4; ++k) {
+            float top = lut2d[((size_t)j0 * n + i0) * 4 + k] * gx + lut2d[((size_t)j0 * n + i1) * 4 + k] * fx;
+            float bot = lut2d[((size_t)j1 * n + i0) * 4 + k] * gx + lut2d[((size_t)j1 * n + i1) * 4 + k] * fx;
+            out[p * 4 + k] = unorm8(top * gy + bot * fy);
+        }
+    }
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -35,6 +35,9 @@ def lib():
         L.orc_colormap_rgb.restype = None
         L.orc_colormap_rgb.argtypes = [_fp, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_float, _bp, _fp]
+        L.orc_colormap_bivariate.restype = None
+        L.orc_colormap_bivariate.argtypes = [_fp, ctypes.c_long, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                             ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _bp]
         L.orc_logf.restype = ctypes.c_float
         L.orc_logf.argtypes = [ctypes.c_float]
         L.orc_expf.restype = ctypes.c_float
@@ -89,6 +92,17 @@ def colormap_scalar(img, lut, vmin, vmax, log, weighted):
     out = np.empty((H, W, 4), dtype=np.uint8)
     L.orc_colormap_scalar(img.ctypes.data_as(_fp), H * W, C, lut.ctypes.data_as(_fp), lut.shape[0],
                           vmin, vmax, int(bool(log)), int(bool(weighted)), out.ctypes.data_as(_bp))
+    return out
+
+
+def colormap_bivariate(img, lut2d, vmin, vmax, dvmin, dvmax, log, weighted):
+    L = lib()
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    lut2d = np.ascontiguousarray(lut2d, dtype=np.float32)
+    H, W, C = img.shape
+    out = np.empty((H, W, 4), dtype=np.uint8)
+    L.orc_colormap_bivariate(img.ctypes.data_as(_fp), H * W, C, lut2d.ctypes.data_as(_fp), lut2d.shape[0], vmin, vmax,
+                             dvmin, dvmax, int(bool(log)), int(bool(weighted)), out.ctypes.data_as(_bp))
     return out
 
 

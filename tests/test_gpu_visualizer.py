@@ -111,11 +111,11 @@ def test_bivariate_splat_values(kats):            # reference test_bivariate_ren
 def test_render_mode_switching_and_errors():      # reference tests/test_render_mode.py
     v = topsy_amd.test(1000, render_resolution=64)
     v.scale = 20.0
-    for mode in ("univariate", "rgb", "rgb-hdr", "univariate"):
+    for mode in ("univariate", "bivariate", "rgb", "rgb-hdr", "univariate"):
         v.render_mode = mode
         result, pres = v.get_sph_image(), v.get_sph_presentation_image()
         assert pres.dtype == (np.float16 if mode.endswith("hdr") else np.uint8) and pres.shape == (64, 64, 4)
-        assert result.shape == ((64, 64, 3) if mode.startswith("rgb") else (64, 64))
+        assert result.shape == ((64, 64, 3) if mode.startswith("rgb") else ((64, 64, 2) if mode == "bivariate" else (64, 64)))
     with pytest.raises(ValueError, match="Invalid render_mode 'invalid'"):
         v.render_mode = "invalid"
     assert v.render_mode == "univariate"
@@ -183,7 +183,8 @@ def test_smoke_entry():
     __graft_entry__.smoke()
 
 
-@pytest.mark.parametrize("mode,quantity", [("univariate", None), ("univariate", "test-quantity"), ("rgb", None), ("rgb-hdr", None)])
+@pytest.mark.parametrize("mode,quantity", [("univariate", None), ("univariate", "test-quantity"), ("rgb", None), ("rgb-hdr", None),
+                                           ("bivariate", "test-quantity"), ("bivariate", None)])
 def test_device_autorange_equals_host_autorange(mode, quantity):
     """autorange from device-side order statistics == autorange(get_image()) on the host."""
     v = topsy_amd.test(20000, render_resolution=256, render_mode=mode)
@@ -199,7 +200,51 @@ def test_device_autorange_equals_host_autorange(mode, quantity):
         v.colormap.update_parameters({"vmin": 0.0, "vmax": 1.0})
         v.colormap.autorange_on_device(S)
         dev = v.colormap.get_parameters()
-        for k in ("vmin", "vmax", "log", "ui_range_linear", "ui_range_log"):
+        for k in ("vmin", "vmax", "log", "ui_range_linear", "ui_range_log", "density_vmin", "density_vmax", "ui_range_density"):
             if k in host:
                 assert np.array_equal(np.asarray(host[k]), np.asarray(dev[k])), (k, host[k], dev[k])
+    v.close()
+
+
+def test_bivariate_render(kats):                  # reference test_bivariate_render :345-446, in full
+    from oracle import oracle_c, oracle_np
+    v = topsy_amd.test(1000, render_resolution=200, render_mode="bivariate")
+    v.quantity_name = "test-quantity"
+    v.scale = 20.0
+    v.rotate(0.0, 0.5)
+    v.render_sph(DrawReason.EXPORT)
+    results = v.get_sph_image()
+    mapped = v.get_sph_presentation_image()
+    assert results.shape == (200, 200, 2) and mapped.shape == (200, 200, 4) and mapped.dtype == np.uint8
+    npt.assert_allclose(results[::20, ::20, 0].ravel(), kats["test_bivariate_render.expect_den"], rtol=2e-3)
+    npt.assert_allclose(results[::20, ::20, 1].ravel(), kats["test_bivariate_render.expect_qty"], atol=1e-4)
+    npt.assert_allclose(mapped[::20, ::20].ravel().astype(int), kats["test_bivariate_render.expect_rgba"], atol=5)
+    # and bit-exact against the oracle on the identical float buffer
+    p = v.colormap.get_parameters()
+    raw = v._sph._context.read_image()[..., :2]
+    want = oracle_c.colormap_bivariate(raw, oracle_np.bivariate_lut(p["colormap_name"]), np.float32(p["vmin"]), np.float32(p["vmax"]),
+                                       np.float32(p["density_vmin"]), np.float32(p["density_vmax"]), p["log"], p["weighted_average"])
+    assert np.array_equal(mapped, want)
+    v.close()
+
+
+@pytest.mark.parametrize("log_scale", [True, False], ids=["log", "linear"])
+def test_bivariate_colormap_vs_software(log_scale):   # reference tests/test_colormap.py:107-141 (software model, atol 5)
+    from scipy.interpolate import RegularGridInterpolator
+    v = topsy_amd.test(100, render_resolution=200)
+    img = np.empty((200, 200, 2), dtype=np.float32)
+    img[:, :, 0] = np.logspace(-3, 0, 200)
+    img[:, :, 1] = np.linspace(0, 1, 200)[:, np.newaxis] * img[:, :, 0]
+    vmin, vmax = (-2.0, 0.0) if log_scale else (0.0, 1.0)
+    v.colormap.update_parameters({"type": "bivariate", "weighted_average": True, "vmin": vmin, "vmax": vmax,
+                                  "density_vmin": -3.0, "density_vmax": 0.0, "log": log_scale})
+    image = v.colormap.sph_raw_output_to_image(img)
+    mapping = v.colormap._impl._generate_mapping_rgba_f32(1000)
+    with np.errstate(divide="ignore"):
+        w = img[..., 1] / img[..., 0]
+        sd = (np.log10(img[..., 0]) + 3.0) / 3.0
+        sv = (np.log10(w) - vmin) / (vmax - vmin) if log_scale else (w - vmin) / (vmax - vmin)
+    pts = np.linspace(0, 1, 1000)
+    soft = np.clip(RegularGridInterpolator((pts, pts), mapping, method="linear")(np.clip(np.stack((sv, sd), axis=-1), 0, 1)), 0, 1)
+    npt.assert_allclose(image.astype(int), (soft * 255).astype(np.uint8).astype(int), atol=5)
     v.close()

@@ -63,6 +63,11 @@ SIGNATURES = {
     "tsp_colormap_scalar": (ctypes.c_int, [_ctx, _fp, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
                                            ctypes.c_int, _u8p]),
     "tsp_colormap_rgb": (ctypes.c_int, [_ctx, ctypes.c_float, ctypes.c_float, ctypes.c_float, _u8p, _fp]),
+    "tsp_colormap_set_lut2d": (ctypes.c_int, [_ctx, _fp, ctypes.c_int]),
+    "tsp_colormap_bivariate": (ctypes.c_int, [_ctx, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                              ctypes.c_int, _u8p]),
+    "tsp_colormap_bivariate_host": (ctypes.c_int, [_ctx, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                                   ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _u8p]),
     "tsp_colormap_scalar_host": (ctypes.c_int, [_ctx, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int,
                                                 ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _u8p]),
     "tsp_colormap_rgb_host": (ctypes.c_int, [_ctx, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
@@ -273,6 +278,26 @@ class Context:
             out = np.empty(shape, dtype=np.uint8)
             _check(self._lib.tsp_colormap_rgb(self._h, float(vmin), float(vmax), float(gamma),
                                               out.ctypes.data_as(_u8p), None))
+        return out
+
+    def colormap_set_lut2d(self, lut_rgba):
+        lut = np.ascontiguousarray(lut_rgba, dtype=np.float32)
+        if lut.ndim != 3 or lut.shape[0] != lut.shape[1] or lut.shape[2] != 4:
+            raise ValueError("2-D LUT must have shape (n, n, 4)")
+        _check(self._lib.tsp_colormap_set_lut2d(self._h, _ptr(lut), lut.shape[0]))
+
+    def colormap_bivariate(self, vmin, vmax, dvmin, dvmax, log, weighted):
+        out = np.empty((self.resolution, self.resolution, 4), dtype=np.uint8)
+        _check(self._lib.tsp_colormap_bivariate(self._h, float(vmin), float(vmax), float(dvmin), float(dvmax), int(bool(log)),
+                                                int(bool(weighted)), out.ctypes.data_as(_u8p)))
+        return out
+
+    def colormap_bivariate_host(self, img, vmin, vmax, dvmin, dvmax, log, weighted):
+        img = np.ascontiguousarray(img, dtype=np.float32)
+        H, W, C = img.shape
+        out = np.empty((H, W, 4), dtype=np.uint8)
+        _check(self._lib.tsp_colormap_bivariate_host(self._h, _ptr(img), H, W, C, float(vmin), float(vmax), float(dvmin),
+                                                     float(dvmax), int(bool(log)), int(bool(weighted)), out.ctypes.data_as(_u8p)))
         return out
 
     def colormap_scalar_host(self, img, lut_rgba, vmin, vmax, log, weighted):

@@ -3,7 +3,7 @@ update asks for a different kind (mirror of reference src/topsy/colormap/__init_
 import numpy as np
 
 from .. import config
-from .implementation import ColormapBase, NoColormap, Colormap, RGBColormap, RGBHDRColormap
+from .implementation import ColormapBase, NoColormap, Colormap, RGBColormap, RGBHDRColormap, BivariateColormap
 
 
 def _all_subclasses(base):

@@ -362,3 +362,83 @@ class RGBHDRColormap(RGBColormap):
     def accepts_parameters(cls, parameters):
         parameters = cls._default_params | parameters
         return parameters.get("type", None) == "rgb" and parameters["hdr"] and parameters["log"]
+
+
+class BivariateColormap(Colormap):
+    """2-D LUT: colour from the (weighted) value, brightness from log10 density (reference
+    colormap/implementation.py:553-605, colormap.wgsl BIVARIATE branch :91-111)."""
+    default_quantity_name = "rho"
+    _default_params = Colormap._default_params | {"density_vmin": 0.0, "density_vmax": 1.0, "ui_range_density": (0.0, 1.0)}
+
+    @classmethod
+    def accepts_parameters(cls, parameters):
+        return parameters.get("type", None) == "bivariate" and (not parameters.get("hdr", False))
+
+    def _generate_mapping_rgba_f32(self, num_points):
+        import matplotlib
+        ramp = np.linspace(0.001, 0.999, num_points)
+        rgba = np.ones((num_points, num_points, 4), dtype=np.float32)
+        rgba[:, :, :] = matplotlib.colormaps[self._params["colormap_name"]](ramp)[:, np.newaxis, :]
+        hsv = matplotlib.colors.rgb_to_hsv(rgba[..., :3])
+        hsv[..., 2] = ramp[np.newaxis, :]                       # brightness follows the density axis
+        fade = np.ones(num_points)
+        fade[3 * num_points // 4:] = np.linspace(1.0, 0.0, num_points // 4)
+        hsv[..., 1] *= fade[np.newaxis, :]                      # desaturate towards white at the bright end
+        rgba[..., :3] = matplotlib.colors.hsv_to_rgb(hsv)
+        return rgba
+
+    def _setup_map_texture(self, num_points=config.COLORMAP_NUM_SAMPLES):
+        name = self._params.get("colormap_name", config.DEFAULT_COLORMAP)
+        if self._lut_for != (name, num_points):
+            self._lut = np.ascontiguousarray(self._generate_mapping_rgba_f32(num_points))
+            self._lut_for = (name, num_points)
+            self._lut_resident = False
+
+    def sph_raw_output_to_content(self, numpy_image):
+        out = numpy_image.copy()
+        if self._params["weighted_average"]:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                out[..., 1] /= out[..., 0]
+        else:
+            out[..., 1] = out[..., 0]
+        return out
+
+    def autorange_vmin_vmax(self, vals):
+        vals = self.sph_raw_output_to_content(vals)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            den = np.log10(vals[..., 0].ravel())
+        den = den[np.isfinite(den)]
+        d_lo, d_hi = np.percentile(den, self.percentile_scaling)
+        self.update_parameters({"density_vmin": d_lo, "density_vmax": d_hi, "ui_range_density": self._finite_range(den)})
+        self._autorange_using_values(vals[..., 1])
+
+    def autorange_on_device(self, mass_scale=1.0):
+        ctx = self._input_texture.context
+        n_fin, n_nonpos = ctx.content_sort(0, mass_scale)
+        n = n_fin - n_nonpos
+        d_lo, d_hi = percentile_from_order_statistics(ctx.content_values, n_nonpos, n, self.percentile_scaling, np.log10)
+        ends = np.log10(ctx.content_values([n_nonpos, n_fin - 1]))
+        self.update_parameters({"density_vmin": d_lo, "density_vmax": d_hi, "ui_range_density": (ends[0], ends[1])})
+        super().autorange_on_device(mass_scale)     # the value axis: ch1/ch0 (weighted) or ch0
+
+    def _ensure_lut_resident(self, ctx):
+        if not getattr(self, "_lut_resident", False) or getattr(ctx, "_lut2d_owner", None) is not self:
+            ctx.colormap_set_lut2d(self._lut)
+            ctx._lut2d_owner = self
+            self._lut_resident = True
+
+    def _run_on_target(self, ctx):
+        p = self._shader_params
+        if self._output_dtype() != np.uint8:
+            raise ValueError(f"Unsupported output format for a LUT colormap: {self._output_format}")
+        self._ensure_lut_resident(ctx)
+        return ctx.colormap_bivariate(p["vmin"], p["vmax"], p["density_vmin"], p["density_vmax"], self._params["log"],
+                                      self._params.get("weighted_average", False))
+
+    def _run_on_host_image(self, ctx, img):
+        p = self._shader_params
+        if self._output_dtype() != np.uint8:
+            raise ValueError(f"Unsupported output format: {self._output_format}")
+        self._ensure_lut_resident(ctx)
+        return ctx.colormap_bivariate_host(img, p["vmin"], p["vmax"], p["density_vmin"], p["density_vmax"], self._params["log"],
+                                           self._params.get("weighted_average", False))

@@ -147,7 +147,7 @@ void tsp_destroy(tsp_context *ctx) {
     (void)hipSetDevice(ctx->device);
     tsp_comm_destroy(ctx);
     free_particles(ctx);
-    void *ptrs[] = {ctx->image, ctx->image64, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->scratch,
+    void *ptrs[] = {ctx->image, ctx->image64, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->lut2d, ctx->scratch,
                     ctx->ws.mid_geom, ctx->ws.mid_w, ctx->ws.huge_geom, ctx->ws.huge_w, ctx->ws.seg_count, ctx->ws.seg_offset,
                     ctx->ws.seg_bbox, ctx->ws.range_prefix, ctx->sort_keys, ctx->sort_keys_alt, ctx->sort_tmp};
     for (void *p : ptrs)
@@ -416,6 +416,33 @@ int tsp_colormap_rgb(tsp_context *ctx, float vmin, float vmax, float gamma, uint
     return TSP_OK;
 }
 
+int tsp_colormap_set_lut2d(tsp_context *ctx, const float *lut_rgba, int n) {
+    TSP_REQUIRE(ctx && lut_rgba && n >= 2 && n <= 4096, TSP_EINVAL, "bad 2-D colormap LUT (n=%d)", n);
+    TSP_HIP(hipSetDevice(ctx->device));
+    if (ctx->lut2d_n != n) {
+        if (ctx->lut2d) TSP_HIP(hipFree(ctx->lut2d));
+        ctx->lut2d = nullptr;
+        TSP_HIP(hipMalloc((void **)&ctx->lut2d, (size_t)n * n * 4 * sizeof(float)));
+        ctx->lut2d_n = n;
+    }
+    TSP_HIP(hipMemcpy(ctx->lut2d, lut_rgba, (size_t)n * n * 4 * sizeof(float), hipMemcpyHostToDevice));
+    return TSP_OK;
+}
+
+int tsp_colormap_bivariate(tsp_context *ctx, float vmin, float vmax, float density_vmin, float density_vmax, int log_scale,
+                           int weighted, uint8_t *out_rgba) {
+    TSP_REQUIRE(ctx && out_rgba, TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(ctx->lut2d, TSP_ESTATE, "tsp_colormap_set_lut2d must be called first");
+    TSP_HIP(hipSetDevice(ctx->device));
+    const int64_t npix = (int64_t)ctx->R * ctx->R;
+    int rc = launch_colormap_bivariate(ctx, ctx->image, npix, ctx->C, vmin, vmax, density_vmin, density_vmax, log_scale, weighted,
+                                       ctx->out8);
+    if (rc) return rc;
+    TSP_HIP(hipMemcpyAsync(out_rgba, ctx->out8, (size_t)npix * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
 static int ensure_scratch(tsp_context *ctx, size_t bytes) {
     if (ctx->scratch_bytes < bytes) {
         if (ctx->scratch) TSP_HIP(hipFree(ctx->scratch));
@@ -439,6 +466,26 @@ int tsp_colormap_scalar_host(tsp_context *ctx, const float *img, int H, int W, i
     uint8_t *d_out = (uint8_t *)ctx->scratch + ((in_bytes + 255) & ~(size_t)255);
     TSP_HIP(hipMemcpyAsync(d_in, img, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = launch_colormap_scalar(ctx, d_in, npix, C, ctx->lut, n_lut, vmin, vmax, log_scale, weighted, d_out)))
+        return rc;
+    TSP_HIP(hipMemcpyAsync(out_rgba, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
+int tsp_colormap_bivariate_host(tsp_context *ctx, const float *img, int H, int W, int C, float vmin, float vmax,
+                                float density_vmin, float density_vmax, int log_scale, int weighted, uint8_t *out_rgba) {
+    TSP_REQUIRE(ctx && img && out_rgba, TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(H > 0 && W > 0 && C >= 2, TSP_EINVAL, "bad image shape %dx%dx%d", H, W, C);
+    TSP_REQUIRE(ctx->lut2d, TSP_ESTATE, "tsp_colormap_set_lut2d must be called first");
+    TSP_HIP(hipSetDevice(ctx->device));
+    const int64_t npix = (int64_t)H * W;
+    const size_t in_bytes = (size_t)npix * C * sizeof(float), out_bytes = (size_t)npix * 4;
+    int rc = ensure_scratch(ctx, in_bytes + out_bytes + 256);
+    if (rc) return rc;
+    float *d_in = (float *)ctx->scratch;
+    uint8_t *d_out = (uint8_t *)ctx->scratch + ((in_bytes + 255) & ~(size_t)255);
+    TSP_HIP(hipMemcpyAsync(d_in, img, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_colormap_bivariate(ctx, d_in, npix, C, vmin, vmax, density_vmin, density_vmax, log_scale, weighted, d_out)))
         return rc;
     TSP_HIP(hipMemcpyAsync(out_rgba, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     TSP_HIP(hipStreamSynchronize(ctx->stream));

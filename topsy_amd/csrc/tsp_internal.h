@@ -84,6 +84,8 @@ struct tsp_context {
     float *outf = nullptr;            // R*R*4 float staging (HDR)
     float *lut = nullptr;             // colormap LUT on device
     int lut_capacity = 0;
+    float *lut2d = nullptr;           // bivariate colormap LUT, n x n x RGBA
+    int lut2d_n = 0;
     void *scratch = nullptr;          // host-image colormap staging
     size_t scratch_bytes = 0;
     uint32_t *sort_keys = nullptr, *sort_keys_alt = nullptr;   // content order statistics (autorange)
@@ -112,6 +114,8 @@ int launch_colormap_scalar(tsp_context *ctx, const float *d_img, int64_t npix, i
                            int n_lut, float vmin, float vmax, int log_scale, int weighted, uint8_t *d_out);
 int launch_colormap_rgb(tsp_context *ctx, const float *d_img, int64_t npix, int C, float vmin, float vmax,
                         float gamma, uint8_t *d_out8, float *d_outf);
+int launch_colormap_bivariate(tsp_context *ctx, const float *d_img, int64_t npix, int C, float vmin, float vmax,
+                             float dvmin, float dvmax, int log_scale, int weighted, uint8_t *d_out);
 int generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int64_t count, uint64_t seed,
                        float h_cap, int with_quantity, int with_rgb);
 int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out);

@@ -19,7 +19,6 @@ logger = logging.getLogger(__name__)
 _VALID_MODES = {"univariate", "bivariate", "rgb", "rgb-hdr", "surface"}
 _UNSUPPORTED_MODES = {
     "surface": "needs the depth-tested occlusion pass and bilateral filter (out of scope, SURVEY.md section 2)",
-    "bivariate": "needs the 2-D LUT colormap (SURVEY.md section 8f rank 4); the splat itself is SPH",
 }
 
 
@@ -58,6 +57,8 @@ class VisualizerBase:
             params.update({"type": "rgb", "hdr": False, "log": True})
         elif render_mode == "rgb-hdr":
             params.update({"type": "rgb", "hdr": True, "log": True})
+        elif render_mode == "bivariate":
+            params.update({"type": "bivariate"})
         else:
             params.update({"type": "density"})
         return params
