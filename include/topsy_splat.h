@@ -150,6 +150,14 @@ int tsp_colormap_scalar_host(tsp_context *ctx, const float *img, int H, int W, i
 int tsp_colormap_rgb_host(tsp_context *ctx, const float *img, int H, int W, int C, float vmin,
                           float vmax, float gamma, uint8_t *out_rgba8, float *out_rgba_f32);
 
+/* Periodic tiling post-pass: replaces the render target by the weighted sum
+ * of n shifted copies of itself -- PeriodicSPH.render + PeriodicSPHAccumulationOverlay (reference
+ * src/topsy/periodic_sph.py:36-88, shaders/overlay.wgsl:18-51): one full-viewport quad per instance
+ * displaced by offsets_xy[k] (clip units, +y up), sampled with a linear filter and clamp-to-edge,
+ * additively blended into a cleared target.  The float64 accumulator keeps the untiled render, so a
+ * later tsp_render(clear = 0) continues from the raw image and the tiling is re-applied afterwards. */
+int tsp_tile_periodic(tsp_context *ctx, int n, const float *offsets_xy, const float *weights);
+
 /* On-device autorange support (replaces the image read-back + host
  * np.percentile of Colormap.autorange_vmin_vmax / _autorange_using_values, reference
  * src/topsy/colormap/implementation.py:381-425, and RGBColormap.autorange_vmin_vmax :512-531).

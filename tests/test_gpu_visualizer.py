@@ -248,3 +248,23 @@ def test_bivariate_colormap_vs_software(log_scale):   # reference tests/test_col
     soft = np.clip(RegularGridInterpolator((pts, pts), mapping, method="linear")(np.clip(np.stack((sv, sd), axis=-1), 0, 1)), 0, 1)
     npt.assert_allclose(image.astype(int), (soft * 255).astype(np.uint8).astype(int), atol=5)
     v.close()
+
+
+def test_periodic_sph_output(kats):               # reference test_periodic_sph_output :243-278
+    from oracle import oracle_np
+    v = topsy_amd.test(1000, render_resolution=200, periodic_tiling=True)
+    assert v.scale == 50.0                        # periodic TestDataLoader: box 100 -> initial half-width 50
+    v.scale = 200.0
+    v.render_sph(DrawReason.EXPORT)
+    result = v.get_sph_image()
+    npt.assert_allclose(result[::20, ::20].flatten(), kats["test_periodic_sph_output.expect"], rtol=1e-1)
+    # rotated, non-integer shifts with fading weights: HIP post-pass == oracle bit for bit
+    v.rotate(0.3, 0.2)
+    v.scale = 130.0
+    v.render_sph(DrawReason.EXPORT)
+    tiled = v._sph._context.read_image()
+    off, w = oracle_np.periodic_instances(v.rotation_matrix, 100.0 / 130.0)
+    v._sph._context.render(*v._sph._get_transform_params(), clear=True)      # the untiled image again
+    raw = v._sph._context.read_image()
+    assert np.array_equal(tiled, oracle_np.periodic_tile(raw, off, w))
+    v.close()

@@ -72,6 +72,7 @@ SIGNATURES = {
                                                 ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _u8p]),
     "tsp_colormap_rgb_host": (ctypes.c_int, [_ctx, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                              ctypes.c_float, ctypes.c_float, _u8p, _fp]),
+    "tsp_tile_periodic": (ctypes.c_int, [_ctx, ctypes.c_int, _fp, _fp]),
     "tsp_content_sort": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_float, _i64p, _i64p]),
     "tsp_content_values": (ctypes.c_int, [_ctx, _i64p, ctypes.c_int, _fp]),
     "tsp_get_stats": (ctypes.c_int, [_ctx, ctypes.POINTER(Stats)]),
@@ -235,6 +236,14 @@ class Context:
         self.set_option("active_channels", img.shape[2])
         self.active_channels = img.shape[2]
         _check(self._lib.tsp_write_image(self._h, _ptr(img)))
+
+    def tile_periodic(self, offsets_xy, weights):
+        """Replace the render target by the weighted sum of shifted copies of itself (clip-space offsets)."""
+        off = _f32(offsets_xy, name="offsets")
+        w = _f32(weights, name="weights")
+        if off.size != 2 * w.size:
+            raise ValueError("offsets must have shape (n, 2) for n weights")
+        _check(self._lib.tsp_tile_periodic(self._h, w.size, _ptr(off), _ptr(w)))
 
     def content_sort(self, kind, scale=1.0):
         """Sort the finite content values on the device; returns (n_finite, n_nonpositive)."""

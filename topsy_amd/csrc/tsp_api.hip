@@ -515,6 +515,12 @@ int tsp_colormap_rgb_host(tsp_context *ctx, const float *img, int H, int W, int 
     return TSP_OK;
 }
 
+int tsp_tile_periodic(tsp_context *ctx, int n, const float *offsets_xy, const float *weights) {
+    TSP_REQUIRE(ctx && n >= 0 && n <= 4096 && (n == 0 || (offsets_xy && weights)), TSP_EINVAL, "bad argument");
+    TSP_HIP(hipSetDevice(ctx->device));
+    return tile_periodic(ctx, n, offsets_xy, weights);
+}
+
 int tsp_content_sort(tsp_context *ctx, int kind, float scale, int64_t *n_finite, int64_t *n_nonpositive) {
     TSP_REQUIRE(ctx && n_finite && n_nonpositive, TSP_EINVAL, "NULL argument");
     TSP_REQUIRE(kind >= 0 && kind <= 3, TSP_EINVAL, "bad content kind %d", kind);

@@ -121,6 +121,7 @@ int generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int64_t
 int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out);
 int measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, double *gbps_out);
 int launch_image_convert(tsp_context *ctx, bool to_float);
+int tile_periodic(tsp_context *ctx, int n, const float *h_offsets, const float *h_weights);
 int content_sort(tsp_context *ctx, int kind, float scale, int64_t *n_finite, int64_t *n_nonpositive);   // image64 -> image (true) or image -> image64 (false)
 int ensure_array(float **p, int64_t n);
 }  // namespace tsp

@@ -43,6 +43,12 @@ class ParticleBuffers:
         logger.info("Uploading position+smoothing+mass arrays")
         ps = ld.get_pos_smooth()
         self.context.upload_particles(ps[:, 0], ps[:, 1], ps[:, 2], ps[:, 3], ld.get_mass())
+        # Load-time spatial ordering (the counterpart of the reference's cell sort at load, loader.py:88-97).
+        # A loader WITH a cell layout hands out per-cell index ranges in its own order, which is already
+        # cell-coherent and must be kept; otherwise the library may reorder: strata keep index prefixes
+        # unbiased for the plain RenderProgression, and later quantity/rgb uploads are permuted by the library.
+        if not hasattr(ld, "_cell_layout") and len(ld) > 1:
+            self.context.reorder_spatial(config.SPATIAL_ORDER_STRATA, 1337)
 
     def __len__(self):
         return len(self._loader)

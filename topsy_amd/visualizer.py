@@ -11,7 +11,7 @@ import logging
 
 import numpy as np
 
-from . import colormap, config, loader, particle_buffers, sph
+from . import colormap, config, loader, particle_buffers, periodic_sph, sph
 from .drawreason import DrawReason
 
 logger = logging.getLogger(__name__)
@@ -28,8 +28,6 @@ class VisualizerBase:
     def __init__(self, data_loader_class=loader.TestDataLoader, data_loader_args=(), data_loader_kwargs={},
                  *, render_resolution=config.DEFAULT_RESOLUTION, periodic_tiling=False,
                  colormap_name=config.DEFAULT_COLORMAP, canvas_class=None, render_mode="univariate", device_id=0):
-        if periodic_tiling:
-            raise NotImplementedError("periodic tiling is an image-space post-pass outside this backend's scope")
         self._render_resolution = render_resolution
         self._sph = None
         self._colormap = None
@@ -43,7 +41,9 @@ class VisualizerBase:
             self.data_loader, render_resolution, device_id,
             self.data_loader.get_render_progression().get_max_particle_regions_per_block())
         self.periodicity_scale = self.data_loader.get_periodicity_scale()
-        self._periodic_tiling = False
+        self._periodic_tiling = periodic_tiling
+        if periodic_tiling and not self.periodicity_scale:
+            raise ValueError("periodic_tiling needs a data loader with a finite periodicity scale")
         self._pending_draw = None
         self._initialize_sph_and_colormap(colormap_name)
 
@@ -77,9 +77,12 @@ class VisualizerBase:
 
     def _initialize_sph_and_colormap(self, colormap_name=None):
         previous = None if self._sph is None else (self._sph.rotation_matrix, self._sph.position_offset, self._sph.scale)
-        sph_class = self._get_sph_class_for_render_mode(self._render_mode)
-        logger.info(f"Using {sph_class.__name__} renderer for render mode '{self._render_mode}'")
-        self._sph = sph_class(self, self._render_resolution)
+        if self._periodic_tiling:
+            self._sph = periodic_sph.PeriodicSPH(self, self._render_resolution)
+        else:
+            sph_class = self._get_sph_class_for_render_mode(self._render_mode)
+            logger.info(f"Using {sph_class.__name__} renderer for render mode '{self._render_mode}'")
+            self._sph = sph_class(self, self._render_resolution)
         self.reset_view(*(previous or (None, None, None)))
         self._sph.invalidate()
         if colormap_name is None:
