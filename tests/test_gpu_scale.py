@@ -196,3 +196,33 @@ def test_synthetic_generator_statistics(native, mips):
     assert np.array_equal(s["x"], d["x"][1234567:1235567]) and np.array_equal(s["h"], d["h"][1234567:1235567])
     c2.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("h_value,label", [(20.0, "all-huge"), (3.0, "all-mid")])
+def test_record_list_overflow_replay(native, mips, h_value, label):
+    """The deferred-footprint lists start small (N/4 mid, N/16 huge records); a frame that needs more
+    reruns kernel S in records-only mode after growing them.  The image must not change because of it."""
+    n, R = 400000, 1024
+    rs = np.random.RandomState(4)
+    pos = (rs.normal(size=(n, 3)) * 40.0).astype(np.float32)
+    h = np.full(n, h_value, dtype=np.float32)              # P = 2 h R / scale = 204.8 px or 30.7 px
+    m = rs.uniform(0.5, 1.5, n).astype(np.float32)
+    q = rs.normal(size=n).astype(np.float32)
+    M, sf = camera(200.0)
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+    ctx.upload_quantity(q)
+    ctx.render(M, sf)                                       # first frame: overflow -> grow -> replay
+    st = ctx.stats()
+    a = ctx.read_image().astype(np.float64)
+    assert st["n_small"] == 0 and (st["n_huge"] if label == "all-huge" else st["n_mid"]) > 65536 * 4
+    assert st["n_small"] + st["n_mid"] + st["n_huge"] + st["n_culled"] == n
+    ctx.render(M, sf)                                       # second frame: lists are large enough now
+    b = ctx.read_image().astype(np.float64)
+    ctx.render(M, sf, flags=native.PIPE_GENERIC)
+    g = ctx.read_image().astype(np.float64)
+    assert rel_close(a[..., 0], g[..., 0], 1e-5) and rel_close(b[..., 0], g[..., 0], 1e-5)
+    tol = 1e-5 * np.abs(g[..., 1]).max()
+    assert np.abs(a[..., 1] - g[..., 1]).max() <= tol * 50      # channel 1 cancels (signed q): scale by sum|terms| ~ 50x max
+    ctx.close()
