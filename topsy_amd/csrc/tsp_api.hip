@@ -127,6 +127,7 @@ int tsp_create(int device_id, int resolution, int n_channels, tsp_context **out)
     TSP_HIP(hipGetDeviceProperties(&prop, device_id));
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     TSP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    TSP_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     for (auto &e : ctx->ev) TSP_HIP(hipEventCreate(&e));
     const size_t npx = (size_t)resolution * resolution;
     TSP_HIP(hipMalloc((void **)&ctx->image, npx * n_channels * sizeof(float)));
@@ -154,6 +155,7 @@ void tsp_destroy(tsp_context *ctx) {
         if (p) (void)hipFree(p);
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -566,6 +568,10 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         if (name[0] == 'm') ctx->mid_split = value > 0 ? (int)value : 1;
         else if (name[0] == 'h') ctx->huge_split = (int)value;
         else ctx->stream_blocks_per_cu = value > 0 ? (int)value : 1;
+        return TSP_OK;
+    }
+    if (!strcmp(name, "overlap_mid_huge")) {
+        ctx->overlap_mid_huge = value != 0;
         return TSP_OK;
     }
     if (!strcmp(name, "use_quantity")) {      // 0: render density-only without dropping the resident q array

@@ -71,7 +71,8 @@ struct tsp_context {
     int R = 0, C = 0, Ccap = 0;       // C = active channels (2 or 4) <= Ccap
     bool use_quantity = true;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipStream_t stream2 = nullptr;    // kernel M runs here, concurrently with kernel H on `stream`
+    hipEvent_t ev[12] = {};
     float *image = nullptr;           // R*R*C float32 render target (what read-back, colormap and reduce see)
     double *image64 = nullptr;        // float64 master copy every kernel accumulates into (rounded once per render)
     float *mips = nullptr;            // 5440 floats
@@ -98,6 +99,7 @@ struct tsp_context {
     float p_small = 11.3f;             // footprints narrower than this many pixels are splatted by kernel S
     int mid_split = 128, huge_split = 0;  // workgroups per image tile (0 = auto)
     int stream_blocks_per_cu = 8;
+    bool overlap_mid_huge = false;    // option: kernels M and H on two streams (measured: no gain at 1.25e8, +6 % at 1e7)
     int cu_count = 256;
     // RCCL
     void *comm = nullptr;

@@ -875,15 +875,23 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     ta.count_frag = ctx->count_fragments ? 1 : 0;
     // corner culling is exact only for value channels (the rgb counter channel counts zero-valued fragments too)
     ta.disc_k2 = (ctx->lut_zero_outside_disc && MODE != TSP_MODE_RGB && !ctx->count_fragments) ? 0.5235f * 0.5235f : 0.0f;
-    TSP_HIP(hipEventRecord(ctx->ev[4], st));
+    // Kernel M (LDS-atomic-bound) and kernel H (VALU-bound) only depend on kernel S and add into the
+    // float64 image with atomics, so they run concurrently on two streams and share the CUs.
+    hipStream_t st_mid = ctx->overlap_mid_huge ? ctx->stream2 : st;
+    if (ctx->overlap_mid_huge) {
+        TSP_HIP(hipEventRecord(ctx->ev[8], st));
+        TSP_HIP(hipStreamWaitEvent(st_mid, ctx->ev[8], 0));
+    }
+    TSP_HIP(hipEventRecord(ctx->ev[4], st_mid));
     if (hc.n_mid > 0) {
         ta.geom = (const float4 *)ws.mid_geom; ta.w = (const float *)ws.mid_w; ta.n_records = (long long)hc.n_mid;
         ta.split = ctx->mid_split;
-        if (WCr == 1) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1>), dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st, ta);
-        else hipLaunchKernelGGL((splat_mid_kernel<MODE, C>), dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st, ta);
+        if (WCr == 1) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1>), dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st_mid, ta);
+        else hipLaunchKernelGGL((splat_mid_kernel<MODE, C>), dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st_mid, ta);
         TSP_HIP(hipGetLastError());
     }
-    TSP_HIP(hipEventRecord(ctx->ev[5], st));
+    TSP_HIP(hipEventRecord(ctx->ev[5], st_mid));
+    TSP_HIP(hipEventRecord(ctx->ev[9], st));
     if (hc.n_huge > 0) {
         ta.geom = (const float4 *)ws.huge_geom; ta.w = (const float *)ws.huge_w; ta.n_records = (long long)hc.n_huge;
         if (MODE == TSP_MODE_RGB) rc = launch_huge<MODE, 3, 4>(ctx, ta, smem_h, (long long)hc.n_huge);
@@ -892,11 +900,12 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         if (rc) return rc;
     }
     TSP_HIP(hipEventRecord(ctx->ev[6], st));
+    if (ctx->overlap_mid_huge) TSP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));     // join: later work on `st` sees both
     TSP_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_stream = ms;
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->stats.ms_mid = ms;
-    TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6])); ctx->stats.ms_huge = ms;
+    TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[6])); ctx->stats.ms_huge = ms;
     return TSP_OK;
 }
 
