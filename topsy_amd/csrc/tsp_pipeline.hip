@@ -92,7 +92,7 @@ struct StreamArgs {
 // WC = channels kept in the LDS window: 1 for a density-only render (channel 1 is identically 0:
 // half the LDS and half the atomics), else the image's channel count.
 template <int MODE, int WC>
-__global__ __launch_bounds__(256, 4) void splat_stream_kernel(StreamArgs a) {
+__global__ __launch_bounds__(256, 5) void splat_stream_kernel(StreamArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;      // extra weights per record
     constexpr int WIN = WinSize<MODE>::value;
