@@ -272,3 +272,57 @@ def test_reference_kats_through_hip(native, mips, golden):
     np.testing.assert_allclose((im[..., 1] / im[..., 0])[::20, ::20].ravel(),
                                kats["test_bivariate_render.expect_qty"], atol=1e-4)
     ctx.close()
+
+
+@pytest.mark.parametrize("R", [1, 2, 8, 33, 65])
+def test_tiny_and_odd_resolutions(native, mips, R):
+    """Resolutions below / not a multiple of every tile size (64-px window, 64x32 and 128x64 tiles)."""
+    from oracle import oracle_np
+    M, sf = oracle_np.transform_matrix(_rot(0.2, 0.1), np.zeros(3), 90.0)
+    pos, h, m, q, _ = make_cloud(3000, seed=21)
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+    ctx.upload_quantity(q)
+    ctx.set_option("count_fragments", 1)
+    ctx.render(M, sf)
+    got = ctx.read_image()
+    want, nfrag = oracle_render(pos, h, m, q, None, 0, M, sf, R, mips)
+    assert ctx.stats()["n_fragments"] == nfrag
+    check_2ch(got, want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
+    ctx.close()
+
+
+def test_single_particles_and_ties(native, mips, golden):
+    """n = 1 (the reference loader's special case), a footprint thousands of pixels wide, footprints whose
+    edges fall exactly on pixel centres, and particles exactly on the z-slab faces."""
+    from oracle import oracle_np
+    R = 128
+    M, sf = oracle_np.transform_matrix(np.eye(3), np.zeros(3), 64.0)       # 1 px = 1 length unit
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    d = golden["testdata_n1.npz"]
+    cases = [
+        (d["pos_smooth"][:, :3], d["pos_smooth"][:, 3], d["mass"]),                                    # TestDataLoader(1)
+        (np.array([[3.0, -7.0, 0.0]], np.float32), np.array([4000.0], np.float32), np.ones(1, np.float32)),    # P = 8000 px
+        # half-widths that put footprint edges exactly on pixel centres (|d| < half is strict)
+        (np.array([[0.5, 0.5, 0.0], [0.0, 0.0, 0.0], [10.5, -3.5, 0.0]], np.float32), np.array([1.0, 0.75, 2.25], np.float32),
+         np.ones(3, np.float32)),
+        # z exactly on the slab faces (clip z = 0 and 1 are kept), just outside (dropped)
+        (np.array([[1.0, 1.0, 64.0], [5.0, 5.0, -64.0], [9.0, 9.0, 64.00001], [20.0, 20.0, -64.00001]], np.float32),
+         np.full(4, 3.0, np.float32), np.ones(4, np.float32)),
+    ]
+    for pos, h, m in cases:
+        pos = np.ascontiguousarray(pos, dtype=np.float32)
+        ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+        for flags in (native.PIPE_DEFAULT, native.PIPE_GENERIC):
+            ctx.set_option("count_fragments", 1)
+            ctx.render(M, sf, flags=flags)
+            got = ctx.read_image()
+            want, nfrag = oracle_render(pos, h.astype(np.float32), m.astype(np.float32), None, None, 0, M, sf, R, mips)
+            assert ctx.stats()["n_fragments"] == nfrag
+            assert np.allclose(got[..., 0], want[..., 0], rtol=1e-5, atol=0)
+            ctx.set_option("count_fragments", 0)
+            ctx.render(M, sf, flags=flags)                  # with the exact corner culling active
+            assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0)
+    ctx.close()
