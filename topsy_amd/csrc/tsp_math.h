@@ -52,17 +52,6 @@ __device__ __forceinline__ Proj project(const Camera &c, float x, float y, float
     return r;
 }
 
-// Conservative candidate pixel interval [lo, hi] for one axis; the exact test is covered().
-__device__ __forceinline__ void cand(float pc, float half, int R, int &lo, int &hi) {
-    float a = __builtin_floorf(pc - half - 0.5f) - 1.0f;
-    float b = __builtin_ceilf(pc + half - 0.5f) + 1.0f;
-    a = a < 0.0f ? 0.0f : a;
-    const float rm = (float)(R - 1);
-    b = b > rm ? rm : b;
-    lo = (int)a;
-    hi = (int)b;     // hi < lo when the interval is empty (b can be < 0 -> negative int)
-}
-
 // Exact interval [lo, hi] of covered pixels along one axis, clipped to the image; lo > hi when empty.
 // Coverage is the canonical test |(i + 0.5) - pc| < half evaluated in float32; it holds on a contiguous
 // run of pixels whose ends lie within one pixel of the real-arithmetic bounds, so three candidate
