@@ -426,46 +426,73 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
             const long long off = s_seg_off[sidx];
             const int cnt = s_seg_cnt[sidx];
             for (int base = 0; base < cnt; base += MT) {
-                const int li = base + tid;
+                // records are dealt to the waves round-robin (wave w takes records w, w + 8, ...): a segment
+                // holds ~100 records on average, and handing them out in runs of 64 would leave six of the
+                // eight waves idle
+                const int li = base + lane * (MT / 64) + wv;
+                // ---- per lane: one record, its tile-clipped pixel ranges and mip level ----------------
                 float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                float gw1 = 0.f, gw2 = 0.f;
+                float gw1 = 0.f, gw2 = 0.f, g_half = 0.f, g_invP = 0.f;
+                int packed = 0;
                 bool hit = false;
                 if (li < cnt && off + li < a.n_records) {
                     g = a.geom[off + li];
-                    gw1 = a.w[(off + li) * NW];
-                    if (NW == 2) gw2 = a.w[(off + li) * NW + 1];
-                    const float half = 0.5f * g.z;
-                    hit = (g.x + half > fx0) && (g.x - half < fx1) && (g.y + half > fy0) && (g.y - half < fy1);
+                    g_half = 0.5f * g.z;
+                    if ((g.x + g_half > fx0) && (g.x - g_half < fx1) && (g.y + g_half > fy0) && (g.y - g_half < fy1)) {
+                        int ilo, ihi, jlo, jhi;
+                        cover_range(g.x, g_half, R, ilo, ihi);
+                        cover_range(g.y, g_half, R, jlo, jhi);
+                        ilo = max(ilo, tx0) - tx0; ihi = min(ihi, tx0 + TILE - 1) - tx0;
+                        jlo = max(jlo, ty0) - ty0; jhi = min(jhi, ty0 + MTILE_H - 1) - ty0;
+                        if (ilo <= ihi && jlo <= jhi) {
+                            hit = true;
+                            gw1 = a.w[(off + li) * NW];
+                            if (NW == 2) gw2 = a.w[(off + li) * NW + 1];
+                            g_invP = 1.0f / g.z;
+                            const int lvl = max(level_for(g.z), 0);
+                            packed = ilo | (ihi << 6) | (jlo << 12) | (jhi << 18) | (lvl << 24);
+                        }
+                    }
                 }
                 unsigned long long mask = __ballot(hit);
+                touched = touched || (mask != 0ull);
+                // ---- per wave: one footprint at a time, its parameters broadcast into scalar registers ----
                 while (mask) {
                     const int src = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;
-                    Proj q;
-                    q.pcx = __shfl(g.x, src); q.pcy = __shfl(g.y, src); q.P = __shfl(g.z, src);
-                    const float w0 = __shfl(g.w, src), w1 = __shfl(gw1, src);
-                    const float w2 = (NW == 2) ? __shfl(gw2, src) : 0.0f;
-                    q.half = 0.5f * q.P; q.invP = 1.0f / q.P;
-                    int ilo, ihi, jlo, jhi;
-                    cover_range(q.pcx, q.half, R, ilo, ihi);
-                    cover_range(q.pcy, q.half, R, jlo, jhi);
-                    ilo = max(ilo, tx0); ihi = min(ihi, tx0 + TILE - 1);
-                    jlo = max(jlo, ty0); jhi = min(jhi, ty0 + MTILE_H - 1);
-                    if (ilo > ihi || jlo > jhi) continue;
-                    touched = true;
-                    const int lvl = level_for(q.P);
+                    const float q_pcx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.x), src));
+                    const float q_pcy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.y), src));
+                    const float q_half = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_half), src));
+                    const float q_invP = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_invP), src));
+                    const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.w), src));
+                    const float w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gw1), src));
+                    const float w2 = (NW == 2) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gw2), src)) : 0.0f;
+                    const int pk = __builtin_amdgcn_readlane(packed, src);
+                    const int ilo = pk & 63, ihi = (pk >> 6) & 63, jlo = (pk >> 12) & 63, jhi = (pk >> 18) & 63, lvl = pk >> 24;
                     const int n = 64 >> lvl, toff = mip_offset(lvl);
-                    for (int jb = jlo; jb <= jhi; jb += 8) {
-                        const int j = jb + ly;
-                        const float dy = ((float)j + 0.5f) - q.pcy;
-                        const int ty = nearest_index((dy + q.half) * q.invP, n);
-                        for (int ib = ilo; ib <= ihi; ib += 8) {
-                            const int i = ib + lx;
-                            if (i <= ihi && j <= jhi) {
-                                const float dx = ((float)i + 0.5f) - q.pcx;
-                                const int tx = nearest_index((dx + q.half) * q.invP, n);
-                                const float kv = T[toff + ty * n + tx];
-                                double *d = tile + (j - ty0) * MSTR + (i - tx0);
+                    // texel row of this lane's pixel row in each 8-row block of the footprint (the tile is 32 rows: <= 4 blocks)
+                    int trow[MTILE_H / 8];
+#pragma unroll
+                    for (int rb = 0; rb < MTILE_H / 8; ++rb) {
+                        trow[rb] = -1;
+                        if (jlo + 8 * rb <= jhi) {
+                            const int j = jlo + 8 * rb + ly;
+                            const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
+                            const int ty = nearest_index((dy + q_half) * q_invP, n);
+                            trow[rb] = (j <= jhi) ? toff + ty * n : -1;
+                        }
+                    }
+                    for (int ib = ilo; ib <= ihi; ib += 8) {
+                        const int i = ib + lx;
+                        const float dx = ((float)(tx0 + i) + 0.5f) - q_pcx;
+                        const int tx = nearest_index((dx + q_half) * q_invP, n);
+                        double *dcol = tile + (jlo + ly) * MSTR + i;
+#pragma unroll
+                        for (int rb = 0; rb < MTILE_H / 8; ++rb) {
+                            if (jlo + 8 * rb > jhi) break;
+                            if (i <= ihi && trow[rb] >= 0) {
+                                const float kv = T[trow[rb] + tx];
+                                double *d = dcol + rb * 8 * MSTR;
                                 if (MODE == TSP_MODE_RGB) {
                                     latomic_add(d, kv * w0); latomic_add(d + MTILE_H * MSTR, kv * w1);
                                     latomic_add(d + 2 * MTILE_H * MSTR, kv * w2); latomic_add(d + 3 * MTILE_H * MSTR, 1.0f);
