@@ -92,14 +92,14 @@ struct StreamArgs {
 // WC = channels kept in the LDS window: 1 for a density-only render (channel 1 is identically 0:
 // half the LDS and half the atomics), else the image's channel count.
 template <int MODE, int WC>
-__global__ __launch_bounds__(256, 5) void splat_stream_kernel(StreamArgs a) {
+__global__ __launch_bounds__(256, 4) void splat_stream_kernel(StreamArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;      // extra weights per record
     constexpr int WIN = WinSize<MODE>::value;
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
     double *win = smem_d;                                            // [WC][WIN*WIN]
     float *T3 = reinterpret_cast<float *>(win + WC * WIN * WIN);     // mip level 3: 8x8
-    __shared__ float s_red[4][4];
+    __shared__ float s_red[4][4], s_mbb[4][4];
     __shared__ int s_cnt[4][2];
     __shared__ long long s_base[2];
 
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256, 5) void splat_stream_kernel(StreamArgs a) {
         // ---- phase 1: coalesced loads, projection, classification ------------------------------
         float pcx[KPT], pcy[KPT], PP[KPT], w0[KPT], w1[KPT], w2[KPT];
         int cls[KPT];
+        int xr[KPT], yr[KPT];          // small footprints: first covered pixel | (number of covered pixels << 16)
         float bx0 = 3.0e38f, by0 = 3.0e38f, bx1 = -3.0e38f, by1 = -3.0e38f;      // small footprints
         float mx0 = 3.0e38f, my0 = 3.0e38f, mx1 = -3.0e38f, my1 = -3.0e38f;      // mid footprints
         int my_mid = 0, my_huge = 0;
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(256, 5) void splat_stream_kernel(StreamArgs a) {
             const int li = k * 256 + tid;
             cls[k] = CLS_NONE;
             pcx[k] = pcy[k] = PP[k] = w0[k] = w1[k] = w2[k] = 0.0f;
+            xr[k] = yr[k] = 0;
             if (li < cnt) {
                 const int64_t i = first + li;
                 const float h = a.p.h[i];
@@ -178,6 +180,9 @@ __global__ __launch_bounds__(256, 5) void splat_stream_kernel(StreamArgs a) {
                     cover_range(pr.pcx, pr.half, R, ilo, ihi);
                     cover_range(pr.pcy, pr.half, R, jlo, jhi);
                     vis = (ilo <= ihi) && (jlo <= jhi);
+                    // a small footprint covers <= 12 pixels per axis and R <= 16384: both fit 16 bits
+                    xr[k] = ilo | (min(ihi - ilo + 1, 0xffff) << 16);
+                    yr[k] = jlo | (min(jhi - jlo + 1, 0xffff) << 16);
                 }
                 if (vis) {
                     const float hh = h * h;
@@ -205,53 +210,22 @@ __global__ __launch_bounds__(256, 5) void splat_stream_kernel(StreamArgs a) {
             }
         }
 
-        // ---- phase 2: block reductions (small bbox, mid bbox, record counts + offsets) ---------
+        // ---- phase 2: the chunk's small-footprint bounding box places the LDS window (uniform) ------
+        // (each exchange has its own LDS scratch, so one barrier per exchange suffices: the barriers of
+        // the following exchanges order its readers before the next chunk's writers)
         bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1);
-        const int mid_incl = wave_incl_scan(my_mid, lane), huge_incl = wave_incl_scan(my_huge, lane);
-        __syncthreads();       // previous chunk's readers of s_* are done
-        if (lane == 63) { s_cnt[wv][0] = mid_incl; s_cnt[wv][1] = huge_incl; }
         if (lane == 0) { s_red[wv][0] = bx0; s_red[wv][1] = by0; s_red[wv][2] = bx1; s_red[wv][3] = by1; }
         __syncthreads();
         bx0 = fminf(fminf(s_red[0][0], s_red[1][0]), fminf(s_red[2][0], s_red[3][0]));
         by0 = fminf(fminf(s_red[0][1], s_red[1][1]), fminf(s_red[2][1], s_red[3][1]));
         bx1 = fmaxf(fmaxf(s_red[0][2], s_red[1][2]), fmaxf(s_red[2][2], s_red[3][2]));
         by1 = fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3]));
-        int mid_before = 0, huge_before = 0, mid_total = 0, huge_total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (w < wv) { mid_before += s_cnt[w][0]; huge_before += s_cnt[w][1]; }
-            mid_total += s_cnt[w][0]; huge_total += s_cnt[w][1];
-        }
-        // mid bbox (only needed when the chunk has mid records)
-        if (mid_total > 0) {
-            mx0 = wave_min(mx0); my0 = wave_min(my0); mx1 = wave_max(mx1); my1 = wave_max(my1);
-            __syncthreads();
-            if (lane == 0) { s_red[wv][0] = mx0; s_red[wv][1] = my0; s_red[wv][2] = mx1; s_red[wv][3] = my1; }
-            __syncthreads();
-            mx0 = fminf(fminf(s_red[0][0], s_red[1][0]), fminf(s_red[2][0], s_red[3][0]));
-            my0 = fminf(fminf(s_red[0][1], s_red[1][1]), fminf(s_red[2][1], s_red[3][1]));
-            mx1 = fmaxf(fmaxf(s_red[0][2], s_red[1][2]), fmaxf(s_red[2][2], s_red[3][2]));
-            my1 = fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3]));
-        }
-        // reserve contiguous runs in the record lists (one atomic per chunk and list)
-        if (tid == 0) {
-            s_base[0] = mid_total ? (long long)atomicAdd(&a.cnt->n_mid, (unsigned long long)mid_total) : 0;
-            s_base[1] = huge_total ? (long long)atomicAdd(&a.cnt->n_huge, (unsigned long long)huge_total) : 0;
-            a.seg_count[c] = mid_total;
-            a.seg_offset[c] = s_base[0];
-            if (mid_total) a.seg_bbox[c] = make_float4(mx0, my0, mx1, my1);
-        }
-        __syncthreads();
-        const long long mid_base = s_base[0], huge_base = s_base[1];
-
-        // ---- phase 3: window placement (uniform) -------------------------------------------------
         if (bx1 >= bx0) {
             const int ix0 = max((int)__builtin_floorf(bx0), 0), ix1 = min((int)__builtin_floorf(bx1), R - 1);
             const int iy0 = max((int)__builtin_floorf(by0), 0), iy1 = min((int)__builtin_floorf(by1), R - 1);
             const bool inside = ix0 >= wox && ix1 < wox + WIN && iy0 >= woy && iy1 < woy + WIN;
             if (!inside) {
                 flush();
-                __syncthreads();
                 // centre the window on the chunk's small-footprint bounding box
                 wox = (ix0 + ix1 + 1 - WIN) / 2;
                 woy = (iy0 + iy1 + 1 - WIN) / 2;
@@ -264,47 +238,72 @@ __global__ __launch_bounds__(256, 5) void splat_stream_kernel(StreamArgs a) {
             dy0 = min(dy0, max(iy0 - woy, 0)); dy1 = max(dy1, min(iy1 - woy, WIN - 1));
         }
 
+        // ---- phase 3: a small footprint that does not fit the window joins the MID list (kernel M
+        //      rasterises any width with the same nearest-mip rule), so phase 4 is LDS-only -----------
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            if (cls[k] != CLS_SMALL) continue;
+            const int ilo = xr[k] & 0xffff, ihi = ilo + (xr[k] >> 16) - 1;
+            const int jlo = yr[k] & 0xffff, jhi = jlo + (yr[k] >> 16) - 1;
+            if (ilo < wox || ihi >= wox + WIN || jlo < woy || jhi >= woy + WIN) {
+                cls[k] = CLS_MID; ++my_mid;
+                const float half = 0.5f * PP[k];
+                mx0 = fminf(mx0, pcx[k] - half); mx1 = fmaxf(mx1, pcx[k] + half);
+                my0 = fminf(my0, pcy[k] - half); my1 = fmaxf(my1, pcy[k] + half);
+            }
+        }
+        // record counts + offsets and the bounding box of the chunk's MID footprints
+        const int mid_incl = wave_incl_scan(my_mid, lane), huge_incl = wave_incl_scan(my_huge, lane);
+        const unsigned long long any_mid = __ballot(my_mid > 0);
+        if (any_mid) { mx0 = wave_min(mx0); my0 = wave_min(my0); mx1 = wave_max(mx1); my1 = wave_max(my1); }
+        if (lane == 63) { s_cnt[wv][0] = mid_incl; s_cnt[wv][1] = huge_incl; }
+        if (lane == 0) { s_mbb[wv][0] = mx0; s_mbb[wv][1] = my0; s_mbb[wv][2] = mx1; s_mbb[wv][3] = my1; }
+        __syncthreads();
+        int mid_before = 0, huge_before = 0, mid_total = 0, huge_total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wv) { mid_before += s_cnt[w][0]; huge_before += s_cnt[w][1]; }
+            mid_total += s_cnt[w][0]; huge_total += s_cnt[w][1];
+        }
+        // reserve contiguous runs in the record lists (one atomic per chunk and list)
+        if (tid == 0) {
+            s_base[0] = mid_total ? (long long)atomicAdd(&a.cnt->n_mid, (unsigned long long)mid_total) : 0;
+            s_base[1] = huge_total ? (long long)atomicAdd(&a.cnt->n_huge, (unsigned long long)huge_total) : 0;
+            a.seg_count[c] = mid_total;
+            a.seg_offset[c] = s_base[0];
+            if (mid_total)
+                a.seg_bbox[c] = make_float4(fminf(fminf(s_mbb[0][0], s_mbb[1][0]), fminf(s_mbb[2][0], s_mbb[3][0])),
+                                            fminf(fminf(s_mbb[0][1], s_mbb[1][1]), fminf(s_mbb[2][1], s_mbb[3][1])),
+                                            fmaxf(fmaxf(s_mbb[0][2], s_mbb[1][2]), fmaxf(s_mbb[2][2], s_mbb[3][2])),
+                                            fmaxf(fmaxf(s_mbb[0][3], s_mbb[1][3]), fmaxf(s_mbb[2][3], s_mbb[3][3])));
+        }
+        __syncthreads();
+        const long long mid_base = s_base[0], huge_base = s_base[1];
+
         // ---- phase 4: rasterise small footprints (one lane per particle, mip 3 nearest) ---------
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             if (cls[k] != CLS_SMALL || !a.emit_small) continue;
             const float half = 0.5f * PP[k], invP = 1.0f / PP[k];
-            int ilo, ihi, jlo, jhi;
-            cover_range(pcx[k], half, R, ilo, ihi);
-            cover_range(pcy[k], half, R, jlo, jhi);
+            const int ilo = xr[k] & 0xffff, ihi = ilo + (xr[k] >> 16) - 1;
+            const int jlo = yr[k] & 0xffff, jhi = jlo + (yr[k] >> 16) - 1;
             for (int j = jlo; j <= jhi; ++j) {
                 const float dy = ((float)j + 0.5f) - pcy[k];
                 const int ty = nearest_index((dy + half) * invP, 8);
-                const int wy = j - woy;
+                double *drow = win + (j - woy) * WIN - wox;
                 for (int i = ilo; i <= ihi; ++i) {
                     const float dx = ((float)i + 0.5f) - pcx[k];
                     const int tx = nearest_index((dx + half) * invP, 8);
                     const float kv = T3[ty * 8 + tx];
-                    const int wx = i - wox;
-                    const bool inw = (unsigned)wx < (unsigned)WIN && (unsigned)wy < (unsigned)WIN;
+                    double *d = drow + i;
                     if (MODE == TSP_MODE_RGB) {
-                        const float v0 = kv * w0[k], v1 = kv * w1[k], v2 = kv * w2[k];
-                        if (inw) {
-                            double *d = win + wy * WIN + wx;
-                            latomic_add(d, v0); latomic_add(d + WIN * WIN, v1);
-                            latomic_add(d + 2 * WIN * WIN, v2); latomic_add(d + 3 * WIN * WIN, 1.0f);
-                        } else {
-                            double *d = a.img + ((size_t)j * R + i) * C;
-                            gatomic_add(d, v0); gatomic_add(d + 1, v1); gatomic_add(d + 2, v2); gatomic_add(d + 3, 1.0);
-                        }
+                        latomic_add(d, kv * w0[k]); latomic_add(d + WIN * WIN, kv * w1[k]);
+                        latomic_add(d + 2 * WIN * WIN, kv * w2[k]); latomic_add(d + 3 * WIN * WIN, 1.0f);
                     } else {
                         if (kv == 0.0f) continue;      // corner texels are exactly 0: adding +-0 changes nothing
                         const float val = kv * w0[k];
-                        const float v1 = val * w1[k];
-                        if (inw) {
-                            double *d = win + wy * WIN + wx;
-                            latomic_add(d, val);
-                            if (WC > 1) latomic_add(d + WIN * WIN, v1);
-                        } else {
-                            double *d = a.img + ((size_t)j * R + i) * C;
-                            gatomic_add(d, val);
-                            if (WC > 1) gatomic_add(d + 1, v1);
-                        }
+                        latomic_add(d, val);
+                        if (WC > 1) latomic_add(d + WIN * WIN, val * w1[k]);
                     }
                 }
             }
