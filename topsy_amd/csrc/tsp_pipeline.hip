@@ -559,9 +559,12 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
         const int j = i >> 6, x = i & 63, j1 = min(j + 1, 63), x1 = min(x + 1, 63);
         Q[i] = make_float4(a.mips[j * 64 + x], a.mips[j * 64 + x1], a.mips[j1 * 64 + x], a.mips[j1 * 64 + x1]);
     }
-    const int bx = tid & 31, by = tid >> 5;           // 4 x PXH pixel block owned by this lane
-    const int px0 = tx0 + 4 * bx, py0 = ty0 + PXH * by;
-    const float sy0 = (float)(ty0 + 2 * PXH * wv), sy1 = sy0 + (float)(2 * PXH);     // this wave's pixel rows
+    // A wave covers a 64 x 4*PXH pixel strip (16 x 4 lanes of 4 x PXH pixels) and the 8 waves tile the
+    // 128 x 16*PXH tile 2 x 4: measured 5 % faster than full-width 128 x 2*PXH strips (more footprints
+    // miss a strip entirely, and 64-256 pixel footprints fill the strips they do reach better)
+    const int sx = tx0 + 64 * (wv & 1), sy = ty0 + 4 * PXH * (wv >> 1);
+    const int px0 = sx + 4 * (lane & 15), py0 = sy + PXH * (lane >> 4);
+    const float sx0 = (float)sx, sx1 = (float)(sx + 64), sy0 = (float)sy, sy1 = (float)(sy + 4 * PXH);
     // pixel-centre coordinates; pixels outside the image get +inf so they are never covered
     float pxc[4], pyc[PXH];
 #pragma unroll
@@ -625,9 +628,9 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
         for (int e = 0; e < nq; ++e) {
             const float4 r4 = qg[e];
             const float pcx = r4.x, pcy = r4.y, half = r4.z, invP = r4.w;
-            {   // this wave's strip (128 x 2*PXH pixels): skip footprints whose square or disc misses it
-                const float sdx = fmaxf(fmaxf(fx0 - pcx, pcx - fx1), 0.0f), sdy = fmaxf(fmaxf(sy0 - pcy, pcy - sy1), 0.0f);
-                if (sdy >= half || (a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * (4.0f * half * half))) continue;
+            {   // this wave's strip: skip footprints whose square or disc misses it
+                const float sdx = fmaxf(fmaxf(sx0 - pcx, pcx - sx1), 0.0f), sdy = fmaxf(fmaxf(sy0 - pcy, pcy - sy1), 0.0f);
+                if (sdx >= half || sdy >= half || (a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * (4.0f * half * half))) continue;
             }
             const float4 wq = qw[e];
             int col[4], row[PXH];
