@@ -15,7 +15,7 @@ with open(f"profiles/{tag}_bench_kernel_stats.csv", "w") as f:
     for r in rows:
         w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 pmc = collections.defaultdict(dict)
-for d in ("pmc_fetch", "pmc_write"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
     p = f"{src}/{d}/run_counter_collection.csv"
     if not os.path.exists(p): continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
