@@ -564,7 +564,7 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         return TSP_OK;
     }
     if (!strcmp(name, "mid_split") || !strcmp(name, "huge_split") || !strcmp(name, "stream_blocks_per_cu")) {
-        TSP_REQUIRE(value >= 0 && value <= 1024, TSP_EINVAL, "%s out of range", name);
+        TSP_REQUIRE(value >= 0 && value <= 4096, TSP_EINVAL, "%s out of range", name);
         if (name[0] == 'm') ctx->mid_split = value > 0 ? (int)value : 1;
         else if (name[0] == 'h') ctx->huge_split = (int)value;
         else ctx->stream_blocks_per_cu = value > 0 ? (int)value : 1;

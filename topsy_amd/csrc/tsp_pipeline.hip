@@ -6,23 +6,24 @@
 // (DESIGN.md section 4): 80 % of particles cover < 8 px but > 90 % of all pixel updates come from the
 // ~1 % of particles wider than 64 px.
 //
-//   kernel S  splat_stream_kernel  streams the SoA particle arrays once (coalesced, 2048-particle
-//             chunks per workgroup, consecutive chunks per workgroup so load-time spatial order gives
-//             screen locality).  Footprints < p_small px are rasterised at once into a 64x64-pixel
-//             LDS window that follows the chunks (ds_add_f32), flushed with one global atomic per
-//             touched pixel.  Wider footprints are not rasterised here: their projected records
+//   kernel S  splat_stream_kernel  streams the SoA particle arrays once (coalesced, 512-particle
+//             chunks, ~10 consecutive chunks per workgroup so load-time spatial order gives screen
+//             locality).  Footprints < p_small px that fit the 64x64-pixel LDS window following the
+//             chunks are rasterised at once (ds_add_f64), flushed with one global atomic per touched
+//             pixel.  All other footprints are not rasterised here: their projected records
 //             (pcx, pcy, P, weights) are appended to the MID list (per-chunk contiguous segments with
 //             a pixel bounding box) or the HUGE list.
-//   kernel M  splat_mid_kernel     one workgroup per (64x64 image tile, split): walks the segments
-//             whose bbox meets the tile; each wave rasterises its records' footprints restricted to
-//             the tile, 8x8 lanes per step, nearest-mip sampling from an LDS copy of the mip pyramid,
-//             ds_add_f32 into the LDS tile (row stride 72: conflict-free for 8x8 lane blocks).
-//   kernel H  splat_huge_kernel    one workgroup per (64x64 tile, split): every lane owns a 4x4 pixel
+//   kernel M  splat_mid_kernel     one workgroup per (64x32 image tile, split): walks the segments
+//             whose bbox meets the tile; every lane prepares one record (tile-clipped pixel ranges,
+//             mip level), then each wave rasterises its records one at a time, parameters broadcast
+//             into scalar registers, 8x8 lanes per step, nearest-mip sampling from an LDS copy of the
+//             mip pyramid, ds_add_f64 into the LDS tile (row stride 72: distinct addresses per step).
+//   kernel H  splat_huge_kernel    one workgroup per (128x64 tile, split): every lane owns a 4x4 pixel
 //             block in registers (no atomics in the loop); records overlapping the tile are compacted
-//             into an LDS queue and evaluated by all 256 lanes with bilinear sampling from an LDS
-//             "quad table" (one ds_read_b128 fetches the 2x2 texel stencil of a pixel).
+//             into an LDS queue and evaluated by the 8 waves (64x16-pixel strips) with bilinear sampling
+//             from an LDS "quad table" (one ds_read_b128 fetches the 2x2 texel stencil of a pixel).
 //
-// All three add into the float32 render target with device-scope atomics only at flush time.
+// All three add into the float64 render target with device-scope atomics only at flush time.
 #include <string.h>
 
 #include <algorithm>
@@ -32,13 +33,14 @@
 
 namespace tsp {
 
-constexpr int CHUNK = 1024;          // particles per chunk
+constexpr int CHUNK = 512;           // particles per chunk
 constexpr int KPT = CHUNK / 256;     // particles per thread per chunk
 constexpr int TILE = 64;             // image tile edge of kernel H (and tile width of kernel M)
 constexpr int MTILE_H = 32;          // tile height of kernel M (64 x 32 pixels per workgroup)
 constexpr int MSTR = 72;             // LDS row stride (doubles) of the mid tile
-// LDS accumulators are DOUBLE: on gfx950 ds_add_f64 costs ~20 clk per wave-instruction while
-// ds_add_f32 costs ~190 (measured, tools/ubench/lds_atomics.hip), and the sums gain precision.
+// LDS accumulators are DOUBLE: on gfx950 a conflict-free ds_add_f64 costs ~9 clk per wave-instruction
+// (~11 clk more per extra lane on the same address) while ds_add_f32 costs ~190 (measured,
+// tools/ubench/lds_partial.hip, lds_atomics.hip), and the sums gain precision.
 template <int MODE> struct WinSize { static constexpr int value = (MODE == TSP_MODE_RGB) ? 48 : 64; };
 
 enum { CLS_NONE = 0, CLS_SMALL = 1, CLS_MID = 2, CLS_HUGE = 3 };
@@ -92,7 +94,7 @@ struct StreamArgs {
 // WC = channels kept in the LDS window: 1 for a density-only render (channel 1 is identically 0:
 // half the LDS and half the atomics), else the image's channel count.
 template <int MODE, int WC>
-__global__ __launch_bounds__(256, 4) void splat_stream_kernel(StreamArgs a) {
+__global__ __launch_bounds__(256, 5) void splat_stream_kernel(StreamArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;      // extra weights per record
     constexpr int WIN = WinSize<MODE>::value;
@@ -858,7 +860,8 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         sa.p = parts;
         sa.ranges = ws.range_prefix; sa.n_ranges = n_ranges; sa.n_chunks = n_chunks;
         const int max_blocks = ctx->cu_count * ctx->stream_blocks_per_cu;
-        sa.chunks_per_block = std::max(1, (n_chunks + max_blocks - 1) / max_blocks);
+        // at least 8 consecutive chunks per workgroup: amortises the window set-up and keeps the window following the chunks
+        sa.chunks_per_block = std::max(8, (n_chunks + max_blocks - 1) / max_blocks);
         const int grid_s = (n_chunks + sa.chunks_per_block - 1) / sa.chunks_per_block;
         sa.cam = cam; sa.mips = ctx->mips; sa.img = ctx->image64;
         sa.mid_geom = (float4 *)ws.mid_geom; sa.mid_w = (float *)ws.mid_w; sa.mid_capacity = ws.mid_capacity;
