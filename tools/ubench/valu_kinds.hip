@@ -34,6 +34,11 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float s) {
                 else if (OP == 14) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(b[i]), "v"(c[i]) : "vcc");
                 else if (OP == 15) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[i]) : "v"(b[i]), "v"(c[i]), "v"(b[(i + 1) & 7]));
                 else if (OP == 16) asm volatile("v_add_f32 %0, %1, %2" : "=v"(a[i]) : "v"(b[i]), "v"(c[i]));
+                else if (OP == 18) asm volatile("v_mul_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf" : "=v"(a[i]) : "v"(b[i]), "v"(c[i]));
+                else if (OP == 19) asm volatile("v_mul_f32_dpp %0, %1, %2 row_ror:4 row_mask:0xf bank_mask:0xf" : "=v"(a[i]) : "v"(b[i]), "v"(c[i]));
+                else if (OP == 20) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b[i]), "v"(c[i]));
+                else if (OP == 21) asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(a[i]) : "v"(b[i]));
+                else if (OP == 22) asm volatile("v_add_u32_dpp %0, %1, %2 row_ror:12 row_mask:0xf bank_mask:0xf" : "=v"(a[i]) : "v"(b[i]), "v"(c[i]));
                 else if (OP == 17) asm volatile("v_max_f32 %0, %1, %2" : "=v"(a[i]) : "v"(b[i]), "v"(c[i]));
             }
         }
@@ -70,5 +75,6 @@ int main() {
     run<4>("v_floor_f32", 1); run<5>("v_cvt_i32_f32", 1); run<6>("v_add_u32", 1); run<12>("v_lshl_add_u32", 1);
     run<7>("v_mul_f32 v,v", 1); run<11>("v_mul_f32 s,v", 1); run<8>("v_fmac_f32", 1); run<9>("v_sub_f32", 1); run<16>("v_add_f32", 1); run<17>("v_max_f32", 1);
     run<10>("v_mov_b32", 1);
+    run<18>("v_mul_f32_dpp quad_perm", 1); run<19>("v_mul_f32_dpp row_ror:4", 1); run<20>("v_fmac_f32_dpp quad_perm", 1); run<21>("v_mov_b32_dpp row_ror:8", 1); run<22>("v_add_u32_dpp row_ror:12", 1);
     return 0;
 }

@@ -530,6 +530,16 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
 // ---------------------------------------------------------------------------------------------
 // kernel H: huge footprints (P >= 64 px), tile gather with bilinear sampling
 // ---------------------------------------------------------------------------------------------
+// v_mov_b32_dpp: read a value from another lane of the same 16-lane row (no LDS traffic)
+template <int N> __device__ __forceinline__ int dpp_row_ror(int v) {          // lane i reads lane (i - N) mod 16 of its row
+    return __builtin_amdgcn_mov_dpp(v, 0x120 + N, 0xf, 0xf, true);
+}
+template <int N> __device__ __forceinline__ float dpp_row_ror(float v) { return __int_as_float(dpp_row_ror<N>(__float_as_int(v))); }
+template <int T> __device__ __forceinline__ int dpp_quad_bcast(int v) {       // every lane of a quad reads the quad's lane T
+    return __builtin_amdgcn_mov_dpp(v, T * 0x55, 0xf, 0xf, true);
+}
+template <int T> __device__ __forceinline__ float dpp_quad_bcast(float v) { return __int_as_float(dpp_quad_bcast<T>(__float_as_int(v))); }
+
 constexpr int HT = 512;              // threads per workgroup of kernel H (8 waves share one quad table)
 constexpr int HTILE_W = 128;         // its tile is 128 pixels wide: 32 lanes x 4 pixels
 
@@ -565,14 +575,21 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
     // 128 x 16*PXH tile 2 x 4: measured 5 % faster than full-width 128 x 2*PXH strips (more footprints
     // miss a strip entirely, and 64-256 pixel footprints fill the strips they do reach better)
     const int sx = tx0 + 64 * (wv & 1), sy = ty0 + 4 * PXH * (wv >> 1);
-    const int px0 = sx + 4 * (lane & 15), py0 = sy + PXH * (lane >> 4);
+    // Lane layout inside the strip: the 16 lanes of a DPP row form a 4 x 4 grid of 4 x 4-pixel blocks (16 x 16
+    // pixels; the wave's four rows sit side by side).  Lane (g, p) = (quad, position in quad) owns the block at
+    // block-column p, block-row g, so the four lanes of a QUAD share their pixel ROWS and the four lanes at the
+    // same quad position share their pixel COLUMNS.  Each lane evaluates ONE column coordinate and ONE row
+    // coordinate per footprint and fetches the other three of each from its partners with v_mov_b32_dpp
+    // (quad_perm broadcast for rows, row_ror:4k for columns) -- 2 + 21 moves instead of 8 evaluations of ~12
+    // instructions.  Because a DPP rotation is relative, a lane's k-th column slot is pixel column (g - k) & 3.
+    static_assert(PXH == 4, "the DPP sharing scheme is laid out for 4 x 4 pixels per lane");
+    const int lg = (lane >> 2) & 3, lp = lane & 3;
+    const int px0 = sx + 16 * (lane >> 4) + 4 * lp, py0 = sy + PXH * lg;
     const float sx0 = (float)sx, sx1 = (float)(sx + 64), sy0 = (float)sy, sy1 = (float)(sy + 4 * PXH);
-    // pixel-centre coordinates; pixels outside the image get +inf so they are never covered
-    float pxc[4], pyc[PXH];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) pxc[t] = (px0 + t < R) ? (float)(px0 + t) + 0.5f : __builtin_inff();
-#pragma unroll
-    for (int t = 0; t < PXH; ++t) pyc[t] = (py0 + t < R) ? (float)(py0 + t) + 0.5f : __builtin_inff();
+    // pixel centre this lane evaluates itself: column slot 0 (= column lg) and row lp; +inf outside the image
+    // so that it is never covered
+    const float pxc_own = (px0 + lg < R) ? (float)(px0 + lg) + 0.5f : __builtin_inff();
+    const float pyc_own = (py0 + lp < R) ? (float)(py0 + lp) + 0.5f : __builtin_inff();
     // Accumulation is two-level so the float32 error stays ~sqrt(run length) * 2^-24 instead of
     // sqrt(n): short runs in `acc`, folded into `tot` (PXH == 4) or, when the registers are needed
     // for the taller pixel block, straight into the render target (PXH == 8).
@@ -637,12 +654,10 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
             const float4 wq = qw[e];
             int col[4], row[PXH];
             float fxs[4], gxs[4], fys[PXH], gys[PXH];
-            float cvx[4], cvy[PXH];               // rgb only: coverage flags for the fragment counter
-            int ncov_x = 0, ncov_y = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            float cvx[4], cvy[PXH];               // coverage flags: rgb fragment counter / fragment statistics only
+            {
                 // canonical texel coordinate: u = (d + half) * invP ; tu = u * 64 - 0.5 (tsp_math.h)
-                const float d = pxc[t] - pcx;
+                const float d = pxc_own - pcx;
                 const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
                 const float u = (d + half) * invP;
                 // clamping tu to [0, 63] reproduces clamp-to-edge: tu < 0 -> texel 0 weight 1,
@@ -650,25 +665,37 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
                 const float tu = __builtin_amdgcn_fmed3f(__builtin_fmaf(u, 64.0f, -0.5f), 0.0f, 63.0f);
                 const float f0 = __builtin_floorf(tu);
                 const float fr = (tu - f0) * cv;        // uncovered column: both weights 0
-                col[t] = (int)f0;
-                fxs[t] = fr;
-                gxs[t] = cv - fr;
-                if (MODE == TSP_MODE_RGB) cvx[t] = cv;
-                ncov_x += (cv != 0.0f);
+                const int c0 = (int)f0;
+                const float g0 = cv - fr;
+                col[0] = c0; fxs[0] = fr; gxs[0] = g0; cvx[0] = cv;
+                col[1] = dpp_row_ror<4>(c0); fxs[1] = dpp_row_ror<4>(fr); gxs[1] = dpp_row_ror<4>(g0);
+                col[2] = dpp_row_ror<8>(c0); fxs[2] = dpp_row_ror<8>(fr); gxs[2] = dpp_row_ror<8>(g0);
+                col[3] = dpp_row_ror<12>(c0); fxs[3] = dpp_row_ror<12>(fr); gxs[3] = dpp_row_ror<12>(g0);
+                if (MODE == TSP_MODE_RGB || a.count_frag) {
+                    cvx[1] = dpp_row_ror<4>(cv); cvx[2] = dpp_row_ror<8>(cv); cvx[3] = dpp_row_ror<12>(cv);
+                }
             }
-#pragma unroll
-            for (int t = 0; t < PXH; ++t) {
-                const float d = pyc[t] - pcy;
+            {
+                const float d = pyc_own - pcy;
                 const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
                 const float v = (d + half) * invP;
                 const float tv = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, 64.0f, -0.5f), 0.0f, 63.0f);
                 const float f0 = __builtin_floorf(tv);
                 const float fr = (tv - f0) * cv;
-                row[t] = ((int)f0) << 6;
-                fys[t] = fr;
-                gys[t] = cv - fr;
-                if (MODE == TSP_MODE_RGB) cvy[t] = cv;
-                ncov_y += (cv != 0.0f);
+                const int r0 = ((int)f0) << 6;
+                const float g0 = cv - fr;
+                row[0] = dpp_quad_bcast<0>(r0); fys[0] = dpp_quad_bcast<0>(fr); gys[0] = dpp_quad_bcast<0>(g0);
+                row[1] = dpp_quad_bcast<1>(r0); fys[1] = dpp_quad_bcast<1>(fr); gys[1] = dpp_quad_bcast<1>(g0);
+                row[2] = dpp_quad_bcast<2>(r0); fys[2] = dpp_quad_bcast<2>(fr); gys[2] = dpp_quad_bcast<2>(g0);
+                row[3] = dpp_quad_bcast<3>(r0); fys[3] = dpp_quad_bcast<3>(fr); gys[3] = dpp_quad_bcast<3>(g0);
+                if (MODE == TSP_MODE_RGB || a.count_frag) {
+                    cvy[0] = dpp_quad_bcast<0>(cv); cvy[1] = dpp_quad_bcast<1>(cv); cvy[2] = dpp_quad_bcast<2>(cv); cvy[3] = dpp_quad_bcast<3>(cv);
+                }
+            }
+            int ncov_x = 0, ncov_y = 0;
+            if (a.count_frag) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { ncov_x += (cvx[t] != 0.0f); ncov_y += (cvy[t] != 0.0f); }
             }
 #pragma unroll
             for (int ty = 0; ty < PXH; ++ty) {
@@ -712,8 +739,9 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
 #pragma unroll
                         for (int tx = 0; tx < 4; ++tx) {
                             const int p = ty * 4 + tx;
-                            if (px0 + tx < R && py0 + ty < R) {
-                                double *d = a.img + ((size_t)(py0 + ty) * R + px0 + tx) * C;
+                            const int gxp = px0 + ((lg - tx) & 3);       // column slot tx
+                            if (gxp < R && py0 + ty < R) {
+                                double *d = a.img + ((size_t)(py0 + ty) * R + gxp) * C;
 #pragma unroll
                                 for (int c = 0; c < NACC; ++c) {
                                     if (acc[p][c] != 0.0f) gatomic_add(d + c, acc[p][c]);
@@ -731,7 +759,7 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
     for (int ty = 0; ty < PXH; ++ty) {
 #pragma unroll
         for (int tx = 0; tx < 4; ++tx) {
-            const int p = ty * 4 + tx, gx = px0 + tx, gy = py0 + ty;
+            const int p = ty * 4 + tx, gx = px0 + ((lg - tx) & 3), gy = py0 + ty;   // column slot tx
             if (gx < R && gy < R) {
                 double *d = a.img + ((size_t)gy * R + gx) * C;
 #pragma unroll
