@@ -62,6 +62,8 @@ struct Workspace {     // per-context scratch of the three-class pipeline (grown
     int64_t seg_capacity = 0;
     int64_t *range_prefix = nullptr;    // device copy of the ranges of the current call
     int64_t range_capacity = 0;
+    int *count_diff = nullptr;          // rgb: (R+1)^2 corner-difference image of the huge footprints' pixel rectangles
+    int *count_band = nullptr;          // rgb: per (64-row band, column) sums of its row-scanned form
 };
 
 }  // namespace tsp

@@ -494,9 +494,9 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                             if (i <= ihi && trow[rb] >= 0) {
                                 const float kv = T[trow[rb] + tx];
                                 double *d = dcol + rb * 8 * MSTR;
-                                if (MODE == TSP_MODE_RGB) {
+                                if (MODE == TSP_MODE_RGB) {     // the counter channel is summed by add_rect_counts()
                                     latomic_add(d, kv * w0); latomic_add(d + MTILE_H * MSTR, kv * w1);
-                                    latomic_add(d + 2 * MTILE_H * MSTR, kv * w2); latomic_add(d + 3 * MTILE_H * MSTR, 1.0f);
+                                    latomic_add(d + 2 * MTILE_H * MSTR, kv * w2);
                                 } else {
                                     const float val = kv * w0;
                                     latomic_add(d, val);
@@ -597,10 +597,8 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
     constexpr int NTOT = REG_TOTALS ? NPX : 1;
     constexpr int FOLD_EVERY = REG_TOTALS ? 64 : 1024;
     float acc[NPX][NACC], tot[NTOT][NACC];
-    float cnt_acc[NPX];              // rgb: fragment counter channel
 #pragma unroll
     for (int p = 0; p < NPX; ++p) {
-        cnt_acc[p] = 0.0f;
 #pragma unroll
         for (int c = 0; c < NACC; ++c) acc[p][c] = 0.0f;
     }
@@ -654,7 +652,7 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
             const float4 wq = qw[e];
             int col[4], row[PXH];
             float fxs[4], gxs[4], fys[PXH], gys[PXH];
-            float cvx[4], cvy[PXH];               // coverage flags: rgb fragment counter / fragment statistics only
+            float cvx[4], cvy[PXH];               // coverage flags: fragment statistics only
             {
                 // canonical texel coordinate: u = (d + half) * invP ; tu = u * 64 - 0.5 (tsp_math.h)
                 const float d = pxc_own - pcx;
@@ -671,7 +669,7 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
                 col[1] = dpp_row_ror<4>(c0); fxs[1] = dpp_row_ror<4>(fr); gxs[1] = dpp_row_ror<4>(g0);
                 col[2] = dpp_row_ror<8>(c0); fxs[2] = dpp_row_ror<8>(fr); gxs[2] = dpp_row_ror<8>(g0);
                 col[3] = dpp_row_ror<12>(c0); fxs[3] = dpp_row_ror<12>(fr); gxs[3] = dpp_row_ror<12>(g0);
-                if (MODE == TSP_MODE_RGB || a.count_frag) {
+                if (a.count_frag) {
                     cvx[1] = dpp_row_ror<4>(cv); cvx[2] = dpp_row_ror<8>(cv); cvx[3] = dpp_row_ror<12>(cv);
                 }
             }
@@ -688,7 +686,7 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
                 row[1] = dpp_quad_bcast<1>(r0); fys[1] = dpp_quad_bcast<1>(fr); gys[1] = dpp_quad_bcast<1>(g0);
                 row[2] = dpp_quad_bcast<2>(r0); fys[2] = dpp_quad_bcast<2>(fr); gys[2] = dpp_quad_bcast<2>(g0);
                 row[3] = dpp_quad_bcast<3>(r0); fys[3] = dpp_quad_bcast<3>(fr); gys[3] = dpp_quad_bcast<3>(g0);
-                if (MODE == TSP_MODE_RGB || a.count_frag) {
+                if (a.count_frag) {
                     cvy[0] = dpp_quad_bcast<0>(cv); cvy[1] = dpp_quad_bcast<1>(cv); cvy[2] = dpp_quad_bcast<2>(cv); cvy[3] = dpp_quad_bcast<3>(cv);
                 }
             }
@@ -715,13 +713,6 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
                 // keep at most one pixel row of quad loads (4 x 4 VGPRs) in flight: without this the
                 // scheduler hoists every ds_read_b128 of the block and spills
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            if (MODE == TSP_MODE_RGB) {
-#pragma unroll
-                for (int ty = 0; ty < PXH; ++ty)
-#pragma unroll
-                    for (int tx = 0; tx < 4; ++tx)
-                        cnt_acc[ty * 4 + tx] = __builtin_fmaf(cvy[ty], cvx[tx], cnt_acc[ty * 4 + tx]);   // += 1 iff covered
             }
             if (a.count_frag) n_frag += (unsigned long long)(ncov_x * ncov_y);
             // fold the short-run accumulators into the totals every 64 footprints: bounds the
@@ -767,7 +758,6 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
                     const float v = (REG_TOTALS ? tot[p < NTOT ? p : 0][c] : 0.0f) + acc[p][c];
                     if (v != 0.0f) gatomic_add(d + c, v);
                 }
-                if (MODE == TSP_MODE_RGB && cnt_acc[p] != 0.0f) gatomic_add(d + 3, cnt_acc[p]);
             }
         }
     }
@@ -795,6 +785,91 @@ static int launch_huge(tsp_context *ctx, TileArgs ta, size_t smem_h, long long n
     ta.split = split;
     ta.tiles_x = htiles_x;
     hipLaunchKernelGGL((splat_huge_kernel<MODE, NACC, PXH>), dim3(htiles * split), dim3(HT), smem_h, ctx->stream, ta);
+    TSP_HIP(hipGetLastError());
+    return TSP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rgb fragment-counter channel of the deferred (MID and HUGE) footprints
+// ---------------------------------------------------------------------------------------------
+// fragment_rgb writes (k r, k g, k b, 1): channel 3 counts the footprint SQUARES covering a pixel, also where
+// the kernel value is exactly 0.  Per footprint that is the indicator of a pixel rectangle, so instead of one add
+// per fragment kernels M and H leave the channel alone (H may then skip whatever lies outside the kernel's disc,
+// M saves a quarter of its LDS atomics) and the rectangles are summed exactly in integers: +-1 at the four corners of each rectangle, then a 2-D prefix
+// sum, added to the float64 render target.
+__global__ __launch_bounds__(256) void rect_count_corners_kernel(const float4 *__restrict__ geom, long long n, int R, int *__restrict__ D) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 g = geom[i];
+    const float half = 0.5f * g.z;
+    int ilo, ihi, jlo, jhi;
+    cover_range(g.x, half, R, ilo, ihi);
+    cover_range(g.y, half, R, jlo, jhi);
+    if (ilo > ihi || jlo > jhi) return;
+    const int S = R + 1;
+    atomicAdd(&D[jlo * S + ilo], 1);
+    atomicAdd(&D[jlo * S + ihi + 1], -1);
+    atomicAdd(&D[(jhi + 1) * S + ilo], -1);
+    atomicAdd(&D[(jhi + 1) * S + ihi + 1], 1);
+}
+
+// inclusive prefix sum along each of the first R rows (one 256-thread workgroup per row)
+__global__ __launch_bounds__(256) void count_row_scan_kernel(int *__restrict__ D, int R) {
+    __shared__ int part[256];
+    const int S = R + 1, tid = threadIdx.x;
+    int *row = D + (size_t)blockIdx.x * S;
+    const int per = (S + 255) / 256, b = tid * per, e = min(b + per, S);
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += row[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;
+    for (int i = b; i < e; ++i) { run += row[i]; row[i] = run; }
+}
+
+constexpr int CBAND = 64;
+// column sums of each band of 64 rows
+__global__ __launch_bounds__(256) void count_band_sum_kernel(const int *__restrict__ D, int R, int *__restrict__ band) {
+    const int i = blockIdx.x * 256 + threadIdx.x, bnd = blockIdx.y;
+    if (i >= R) return;
+    const int S = R + 1, j0 = bnd * CBAND, j1 = min(j0 + CBAND, R);
+    int sum = 0;
+    for (int j = j0; j < j1; ++j) sum += D[(size_t)j * S + i];
+    band[(size_t)bnd * R + i] = sum;
+}
+// finish the prefix sum down the columns and add the counts into channel 3
+__global__ __launch_bounds__(256) void count_apply_kernel(const int *__restrict__ D, const int *__restrict__ band, int R, double *__restrict__ img) {
+    const int i = blockIdx.x * 256 + threadIdx.x, bnd = blockIdx.y;
+    if (i >= R) return;
+    const int S = R + 1, j0 = bnd * CBAND, j1 = min(j0 + CBAND, R);
+    long long run = 0;
+    for (int b = 0; b < bnd; ++b) run += band[(size_t)b * R + i];
+    for (int j = j0; j < j1; ++j) {
+        run += D[(size_t)j * S + i];
+        if (run != 0) img[((size_t)j * R + i) * 4 + 3] += (double)run;
+    }
+}
+
+static int add_rect_counts(tsp_context *ctx, const float4 *mid_geom, long long n_mid, const float4 *huge_geom, long long n_huge) {
+    Workspace &ws = ctx->ws;
+    const int R = ctx->R, S = R + 1, nb = (R + CBAND - 1) / CBAND;
+    if (!ws.count_diff) {
+        TSP_HIP(hipMalloc((void **)&ws.count_diff, (size_t)S * S * sizeof(int)));
+        TSP_HIP(hipMalloc((void **)&ws.count_band, (size_t)nb * R * sizeof(int)));
+    }
+    hipStream_t st = ctx->stream;
+    TSP_HIP(hipMemsetAsync(ws.count_diff, 0, (size_t)S * S * sizeof(int), st));
+    if (n_mid > 0) hipLaunchKernelGGL(rect_count_corners_kernel, dim3((unsigned)((n_mid + 255) / 256)), dim3(256), 0, st, mid_geom, n_mid, R, ws.count_diff);
+    if (n_huge > 0) hipLaunchKernelGGL(rect_count_corners_kernel, dim3((unsigned)((n_huge + 255) / 256)), dim3(256), 0, st, huge_geom, n_huge, R, ws.count_diff);
+    hipLaunchKernelGGL(count_row_scan_kernel, dim3(R), dim3(256), 0, st, ws.count_diff, R);
+    hipLaunchKernelGGL(count_band_sum_kernel, dim3((R + 255) / 256, nb), dim3(256), 0, st, ws.count_diff, R, ws.count_band);
+    hipLaunchKernelGGL(count_apply_kernel, dim3((R + 255) / 256, nb), dim3(256), 0, st, ws.count_diff, ws.count_band, R, ctx->image64);
     TSP_HIP(hipGetLastError());
     return TSP_OK;
 }
@@ -869,14 +944,15 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     const bool second_channel = (MODE == TSP_MODE_DEPTH) || (MODE == TSP_MODE_RGB) || (ctx->p.q != nullptr && ctx->use_quantity);
     const int WCr = (MODE == TSP_MODE_RGB) ? 4 : (second_channel ? 2 : 1);
     const size_t smem_s = (size_t)WCr * WIN * WIN * sizeof(double) + 64 * sizeof(float);
-    const size_t smem_m = (size_t)WCr * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float);
+    constexpr int WCM = (MODE == TSP_MODE_RGB) ? 3 : C;      // LDS tile channels of kernel M (rgb: values only)
+    const size_t smem_m = (size_t)(WCr == 1 ? 1 : WCM) * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float);
     const int mtiles_y = (ctx->R + MTILE_H - 1) / MTILE_H;
     const size_t smem_h = (size_t)(64 * 64 + 512) * sizeof(float4);
     static bool attr_set[3] = {false, false, false};
     if (!attr_set[MODE]) {
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WIN * WIN * sizeof(double) + 256)));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WIN * WIN * sizeof(double) + 256)));
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, WCM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
         attr_set[MODE] = true;
     }
@@ -933,8 +1009,9 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     ta.seg_count = ws.seg_count; ta.seg_offset = ws.seg_offset; ta.seg_bbox = ws.seg_bbox; ta.n_chunks = n_chunks;
     ta.cam = cam; ta.mips = ctx->mips; ta.img = ctx->image64; ta.cnt = ctx->counters; ta.tiles_x = tiles_x;
     ta.count_frag = ctx->count_fragments ? 1 : 0;
-    // corner culling is exact only for value channels (the rgb counter channel counts zero-valued fragments too)
-    ta.disc_k2 = (ctx->lut_zero_outside_disc && MODE != TSP_MODE_RGB && !ctx->count_fragments) ? 0.5235f * 0.5235f : 0.0f;
+    // corner culling is exact for the value channels; the rgb counter channel (which also counts zero-valued
+    // fragments) is not touched by kernel H at all: add_rect_counts() sums the footprint rectangles instead
+    ta.disc_k2 = (ctx->lut_zero_outside_disc && !ctx->count_fragments) ? 0.5235f * 0.5235f : 0.0f;
     // Kernel M (LDS-atomic-bound) and kernel H (VALU-bound) only depend on kernel S and add into the
     // float64 image with atomics, so they run concurrently on two streams and share the CUs.
     hipStream_t st_mid = ctx->overlap_mid_huge ? ctx->stream2 : st;
@@ -947,7 +1024,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         ta.geom = (const float4 *)ws.mid_geom; ta.w = (const float *)ws.mid_w; ta.n_records = (long long)hc.n_mid;
         ta.split = ctx->mid_split;
         if (WCr == 1) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1>), dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st_mid, ta);
-        else hipLaunchKernelGGL((splat_mid_kernel<MODE, C>), dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st_mid, ta);
+        else hipLaunchKernelGGL((splat_mid_kernel<MODE, WCM>), dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st_mid, ta);
         TSP_HIP(hipGetLastError());
     }
     TSP_HIP(hipEventRecord(ctx->ev[5], st_mid));
@@ -958,6 +1035,10 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         else if (second_channel) rc = launch_huge<MODE, 2, 4>(ctx, ta, smem_h, (long long)hc.n_huge);
         else rc = launch_huge<MODE, 1, 4>(ctx, ta, smem_h, (long long)hc.n_huge);   // 4x8 px/lane measured slower (spills, larger tiles)
         if (rc) return rc;
+    }
+    if (MODE == TSP_MODE_RGB && (hc.n_mid > 0 || hc.n_huge > 0)) {
+        if (ctx->overlap_mid_huge) TSP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));
+        if ((rc = add_rect_counts(ctx, (const float4 *)ws.mid_geom, (long long)hc.n_mid, (const float4 *)ws.huge_geom, (long long)hc.n_huge))) return rc;
     }
     TSP_HIP(hipEventRecord(ctx->ev[6], st));
     if (ctx->overlap_mid_huge) TSP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));     // join: later work on `st` sees both
