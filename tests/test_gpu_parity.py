@@ -326,3 +326,43 @@ def test_single_particles_and_ties(native, mips, golden):
             ctx.render(M, sf, flags=flags)                  # with the exact corner culling active
             assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0)
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["weighted", "rgb", "depth"])
+def test_scattered_small_footprints_leave_the_window(native, mips, mode):
+    """Unordered particles with footprints of 0-11 px spread over a 1024^2 image: a 512-particle chunk spans far
+    more than kernel S's 64-px LDS window, so most of them take the MID-list route (kernel M, mip 3); the counter
+    channel of those rgb footprints comes from the rectangle sum.  Everything must still match the oracle."""
+    from oracle import oracle_np
+    R = 1024
+    M, sf = oracle_np.transform_matrix(_rot(0.4, 0.15), np.zeros(3), 100.0)
+    rs = np.random.RandomState(77)
+    n = 60000
+    pos = rs.uniform(-95.0, 95.0, size=(n, 3)).astype(np.float32)
+    h = np.exp(rs.uniform(np.log(0.01), np.log(1.05), size=n)).astype(np.float32)      # P = 2 h R / scale <= 10.8 px
+    m = rs.uniform(0.5, 2.0, size=n).astype(np.float32)
+    q = rs.normal(size=n).astype(np.float32)
+    rgb = rs.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32)
+    ctx = native.Context(R, 4 if mode == "rgb" else 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, None if mode == "rgb" else m)
+    if mode == "rgb":
+        ctx.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
+        ctx.render(M, sf, mode=native.MODE_RGB)
+        want, _ = oracle_render(pos, h, rgb[:, 0].copy(), rgb[:, 1].copy(), rgb[:, 2].copy(), 2, M, sf, R, mips)
+        got = ctx.read_image()
+        assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=0)
+        assert np.array_equal(got[..., 3], want[..., 3])
+    elif mode == "depth":
+        ctx.render(M, sf, mode=native.MODE_DEPTH)
+        want, _ = oracle_render(pos, h, m, None, None, 1, M, sf, R, mips)
+        assert np.allclose(ctx.read_image(), want, rtol=1e-5, atol=0)
+    else:
+        ctx.upload_quantity(q)
+        ctx.render(M, sf, mode=native.MODE_WEIGHTED)
+        want, _ = oracle_render(pos, h, m, q, None, 0, M, sf, R, mips)
+        check_2ch(ctx.read_image(), want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
+    st = ctx.stats()
+    assert st["n_huge"] == 0 and st["n_mid"] > n // 4 and st["n_small"] > 0          # all are "small" by width
+    assert st["n_small"] + st["n_mid"] + st["n_culled"] == n
+    ctx.close()
