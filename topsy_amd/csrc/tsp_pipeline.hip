@@ -542,6 +542,7 @@ template <int T> __device__ __forceinline__ float dpp_quad_bcast(float v) { retu
 
 constexpr int HT = 512;              // threads per workgroup of kernel H (8 waves share one quad table)
 constexpr int HTILE_W = 128;         // its tile is 128 pixels wide: 32 lanes x 4 pixels
+constexpr int HDEAL = 4;             // records per dealing run of kernel H
 
 // NACC = value channels accumulated (1: density only, 2: density + weighted/depth, 3: rgb);
 // PXH  = pixel rows per lane (4 or 8): the per-axis setup (12 instructions per row/column) is shared
@@ -610,9 +611,13 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
     int since_fold = 0;
     __syncthreads();
 
-    for (long long base = (long long)sp * 256; base < a.n_records; base += (long long)a.split * 256) {
+    // Records are dealt to the `split` workgroups of a tile in runs of HDEAL: consecutive records are spatial
+    // neighbours (they come from consecutive chunks), so a workgroup's batch of 256 is made of 256 / HDEAL runs
+    // taken `split` runs apart -- every workgroup sees an even sample of the tile's footprints
+    const long long n_runs = (a.n_records + HDEAL - 1) / HDEAL;
+    for (long long run0 = 0; run0 * a.split < n_runs; run0 += 256 / HDEAL) {
         // ---- waves 0-3 test 256 records against the tile and compact the hits into the LDS queue ----
-        const long long ri = base + tid;
+        const long long ri = ((run0 + (tid & 255) / HDEAL) * a.split + sp) * HDEAL + (tid & (HDEAL - 1));
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         bool hit = false;
         if (tid < 256 && ri < a.n_records) {
