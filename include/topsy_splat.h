@@ -95,6 +95,12 @@ int tsp_generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int
  * int64) receives new->old indices.  Later tsp_upload_quantity/rgb calls are given in the OLD
  * order and permuted by the library. */
 int tsp_reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out);
+/* First index of every stratum of the last tsp_reorder_spatial call, plus the particle count:
+ * n_strata + 1 ascending int64 values.  A contiguous index range is an unbiased spatial sample only
+ * when it is a union of whole strata, so the progressive renderer ends its blocks on these offsets
+ * (the reference gets the same property from its per-cell random order, src/topsy/progressive_render.py:152-187).
+ * Returns the number of values written (<= capacity), 0 when the particles were never reordered. */
+int tsp_get_strata_offsets(tsp_context *ctx, int64_t *offsets_out, int capacity);
 
 /* Copy resident particle arrays back (testing / fixtures). Any pointer may be NULL. */
 int tsp_download_particles(tsp_context *ctx, float *x, float *y, float *z, float *h, float *mass,

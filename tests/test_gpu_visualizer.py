@@ -141,7 +141,12 @@ def test_progressive_frames_fold_mass_scale():
     timer.add_block = lambda ms: real_add(40.0)
     v.invalidate()
     v.draw(DrawReason.CHANGE)
-    assert v._sph.last_render_mass_scale == pytest.approx(4.0, rel=1e-3)
+    # the library reordered the particles into strata: the block was rounded to whole strata (unbiased sample)
+    bounds = v.particle_buffers.block_boundaries
+    drawn = rp._start_index
+    assert len(bounds) == 33 and bounds[0] == 0 and bounds[-1] == 200000 and drawn in set(bounds.tolist())
+    assert abs(drawn - 50000) < 200000 // 32
+    assert v._sph.last_render_mass_scale == pytest.approx(200000 / drawn, rel=1e-12)
     partial = v._sph.get_image()             # scaled by N/N_drawn
     ratio = partial[..., 0].sum() / full[..., 0].sum()
     assert 0.97 < ratio < 1.03
@@ -309,4 +314,34 @@ def test_cell_progression_multi_range_blocks():
     mask = culled[..., 0] > 1e-3 * culled[..., 0].max()
     assert mask.sum() > 1000
     npt.assert_allclose(culled[..., 0][mask], everything[..., 0][mask], rtol=0.05)
+    v.close()
+
+
+def test_first_interactive_block_is_a_whole_stratum():
+    """A device-resident snapshot of 5e6 particles: the first interactive block (1e5 requested) is rounded up to
+    one stratum (~1.6e5), and that preview -- scaled by N/N_drawn -- carries the mass of the full image to 2 %,
+    which a spatially compact index range would not."""
+    v = topsy_amd.synthetic_on_device(5_000_000, render_resolution=256)
+    v.scale = 200.0
+    full = v._sph.get_image().copy()
+    rp = v._sph._render_progression
+    bounds = v.particle_buffers.block_boundaries
+    assert len(bounds) == 33 and (np.diff(bounds) > 0).all() and bounds[-1] == 5_000_000
+    assert abs(np.diff(bounds) / (5_000_000 / 32) - 1.0).max() < 0.02        # uniform random strata
+    timer = v._sph._render_timer
+    real_add = timer.add_block
+    timer.add_block = lambda ms: real_add(40.0)           # one block per frame
+    rp._recommended_num_particles_to_render = 100000      # the reference's first-frame guess (config.py:7)
+    v.invalidate()
+    v.draw(DrawReason.CHANGE)
+    assert rp._start_index == bounds[1]
+    preview = v._sph.get_image()
+    assert abs(preview[..., 0].sum() / full[..., 0].sum() - 1.0) < 0.02
+    # the preview is not confined to a corner: its centre of light agrees with the full image's to 2 px
+    jj, ii = np.mgrid[0:256, 0:256]
+    for img in (preview, full):
+        w = img[..., 0] / img[..., 0].sum()
+        img_c = ((w * ii).sum(), (w * jj).sum())
+        if img is preview: c0 = img_c
+    assert abs(c0[0] - img_c[0]) < 2.0 and abs(c0[1] - img_c[1]) < 2.0
     v.close()

@@ -54,6 +54,7 @@ SIGNATURES = {
     "tsp_generate_synthetic": (ctypes.c_int, [_ctx, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64,
                                               ctypes.c_float, ctypes.c_int, ctypes.c_int]),
     "tsp_reorder_spatial": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_uint64, _i64p]),
+    "tsp_get_strata_offsets": (ctypes.c_int, [_ctx, _i64p, ctypes.c_int]),
     "tsp_download_particles": (ctypes.c_int, [_ctx] + [_fp] * 9),
     "tsp_num_particles": (ctypes.c_int64, [_ctx]),
     "tsp_render": (ctypes.c_int, [_ctx, _fp, ctypes.c_float, _i64p, _i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -192,6 +193,12 @@ class Context:
         _check(self._lib.tsp_reorder_spatial(self._h, n_strata, seed,
                                              None if perm is None else perm.ctypes.data_as(_i64p)))
         return perm
+
+    def strata_offsets(self):
+        """First index of every stratum of the last reorder_spatial call, then n (empty if never reordered)."""
+        buf = np.empty(4098, dtype=np.int64)
+        k = int(self._lib.tsp_get_strata_offsets(self._h, buf.ctypes.data_as(_i64p), len(buf)))
+        return buf[:k].copy()
 
     def download_particles(self, names=("x", "y", "z", "h", "mass")):
         order = ("x", "y", "z", "h", "mass", "q", "r", "g", "b")

@@ -85,6 +85,7 @@ static void free_particles(tsp_context *ctx) {
     if (p.perm) (void)hipFree(p.perm);
     p.perm = nullptr;
     p.n = 0;
+    ctx->strata_offsets.clear();
 }
 
 }  // namespace tsp
@@ -237,6 +238,13 @@ int tsp_generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int
     TSP_HIP(hipSetDevice(ctx->device));
     free_particles(ctx);
     return generate_synthetic(ctx, n_total, first, count, seed, h_cap, with_quantity, with_rgb);
+}
+
+int tsp_get_strata_offsets(tsp_context *ctx, int64_t *offsets_out, int capacity) {
+    if (!ctx || !offsets_out || capacity <= 0) return 0;
+    const int n = (int)std::min<size_t>(ctx->strata_offsets.size(), (size_t)capacity);
+    for (int i = 0; i < n; ++i) offsets_out[i] = ctx->strata_offsets[(size_t)i];
+    return n;
 }
 
 int tsp_reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out) {

@@ -188,6 +188,18 @@ __global__ void gather_u32_kernel(const uint32_t *__restrict__ src, const uint32
         dst[i] = src[idx[i]];
 }
 
+// offsets[s] = first index whose stratum (key >> 48) is >= s, for s = 0 .. n_strata (offsets[n_strata] = n)
+__global__ void strata_offsets_kernel(const uint64_t *__restrict__ keys, int64_t n, int n_strata, int64_t *__restrict__ offsets) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > n_strata) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)(keys[mid] >> 48) < (int64_t)s) lo = mid + 1; else hi = mid;
+    }
+    offsets[s] = lo;
+}
+
 int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out) {
     Particles &p = ctx->p;
     const int64_t n = p.n;
@@ -221,6 +233,16 @@ int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm
     void *tmp = nullptr;
     TSP_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
     TSP_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, n, 0, 60, st));
+    {   // stratum boundaries in the new order (keys2 holds the sorted keys)
+        int64_t *d_off = nullptr;
+        TSP_HIP(hipMalloc((void **)&d_off, (size_t)(n_strata + 1) * sizeof(int64_t)));
+        hipLaunchKernelGGL(strata_offsets_kernel, dim3((n_strata + 256) / 256), dim3(256), 0, st, keys2, n, n_strata, d_off);
+        TSP_HIP(hipGetLastError());
+        ctx->strata_offsets.assign((size_t)n_strata + 1, 0);
+        TSP_HIP(hipMemcpyAsync(ctx->strata_offsets.data(), d_off, (size_t)(n_strata + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        TSP_HIP(hipStreamSynchronize(st));
+        TSP_HIP(hipFree(d_off));
+    }
     TSP_HIP(hipStreamSynchronize(st));
     TSP_HIP(hipFree(tmp));
     TSP_HIP(hipFree(keys));

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <vector>
 #include <stdio.h>
 #include <string>
 
@@ -96,6 +98,7 @@ struct tsp_context {
     size_t sort_tmp_bytes = 0;
     int64_t sort_capacity = 0, sorted_count = 0;
     tsp_stats stats = {};
+    std::vector<int64_t> strata_offsets;   // first index of every stratum of the last reorder_spatial, then n
     bool count_fragments = false;
     // pipeline tuning (tsp_set_option)
     float p_small = 11.3f;             // footprints narrower than this many pixels are splatted by kernel S

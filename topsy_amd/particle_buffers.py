@@ -25,6 +25,7 @@ class ParticleBuffers:
         self._have_rgb = False
         self._last_ranges = (None, None)
         self._max_draw_calls_per_buffer = max_draw_calls_per_buffer
+        self.block_boundaries = None          # stratum offsets when the library reordered the particles
         # one 4-channel-capable context serves SPH, DepthSPH and RGBSPH (the active channel count
         # follows the render mode)
         self.context = _native.Context(resolution, 4, device_id)
@@ -38,7 +39,8 @@ class ParticleBuffers:
                                             with_rgb=True)
             self._have_rgb = True
             if ld.spatial_order:
-                self.context.reorder_spatial(config.SPATIAL_ORDER_STRATA, ld.seed)
+                self.context.reorder_spatial(self._num_strata(ld.count), ld.seed)
+                self.block_boundaries = self.context.strata_offsets()
             return
         logger.info("Uploading position+smoothing+mass arrays")
         ps = ld.get_pos_smooth()
@@ -48,7 +50,15 @@ class ParticleBuffers:
         # cell-coherent and must be kept; otherwise the library may reorder: strata keep index prefixes
         # unbiased for the plain RenderProgression, and later quantity/rgb uploads are permuted by the library.
         if not hasattr(ld, "_cell_layout") and len(ld) > 1:
-            self.context.reorder_spatial(config.SPATIAL_ORDER_STRATA, 1337)
+            self.context.reorder_spatial(self._num_strata(len(ld)), 1337)
+            self.block_boundaries = self.context.strata_offsets()
+
+    @staticmethod
+    def _num_strata(n):
+        """Strata of the load-time ordering: at least SPATIAL_ORDER_STRATA, more for large snapshots so that one
+        stratum (the smallest unbiased block) stays near MAX_PARTICLES_PER_STRATUM (measured: 128 strata cost
+        0.1 ms of a 40 ms frame at 1.25e8 particles, 400 strata 0.5 ms)."""
+        return int(min(max(config.SPATIAL_ORDER_STRATA, -(-n // config.MAX_PARTICLES_PER_STRATUM)), config.SPATIAL_ORDER_MAX_STRATA))
 
     def __len__(self):
         return len(self._loader)

@@ -53,6 +53,9 @@ class SPH:
             self._render_progression = share_render_progression
         else:
             self._render_progression = visualizer.data_loader.get_render_progression()
+            boundaries = getattr(visualizer.particle_buffers, "block_boundaries", None)
+            if boundaries is not None and hasattr(self._render_progression, "set_block_boundaries"):
+                self._render_progression.set_block_boundaries(boundaries)
         self.scale = config.DEFAULT_SCALE
         self.min_pixels = 0.0
         self.max_pixels = np.inf
