@@ -81,7 +81,8 @@ def main():
     ctx.generate_synthetic(n_total, first=rank * n_per, count=n_per, seed=1337, h_cap=h_cap,
                            with_quantity=args.mode == "weighted", with_rgb=args.mode == "rgb")
     if not args.no_reorder:
-        ctx.reorder_spatial(32, 1337)       # load-time ordering (config.SPATIAL_ORDER_STRATA)
+        from topsy_amd.particle_buffers import ParticleBuffers
+        ctx.reorder_spatial(ParticleBuffers._num_strata(n_per), 1337)       # load-time ordering, as the product path does
     t_setup = time.time() - t_setup
 
     if world > 1:
@@ -216,7 +217,8 @@ def hcapped_line(args, ctx, n_total, n_per, rank, M, sf, mode, measured_peak, ca
     ctx.generate_synthetic(n_total, first=rank * n_per, count=n_per, seed=1337, h_cap=cap_px * args.scale / (2.0 * R),
                            with_quantity=args.mode == "weighted", with_rgb=args.mode == "rgb")
     if not args.no_reorder:
-        ctx.reorder_spatial(32, 1337)
+        from topsy_amd.particle_buffers import ParticleBuffers
+        ctx.reorder_spatial(ParticleBuffers._num_strata(n_per), 1337)
     ms, st = [], []
     for i in range(frames + 1):
         t = ctx.render(M, sf, clear=True, mode=mode)
