@@ -49,7 +49,14 @@ enum {
 /* Pipeline selection for tsp_render (flags argument). 0 = default (fast three-class pipeline). */
 enum {
     TSP_PIPE_DEFAULT = 0,
-    TSP_PIPE_GENERIC = 1   /* single generic kernel, global atomics only (cross-check / debugging) */
+    TSP_PIPE_GENERIC = 1,  /* single generic kernel, global atomics only (cross-check / debugging) */
+    /* Kernel-texture sampling rule.  The default reproduces every golden vector of the
+     * reference's tests: bilinear on mip 0 when the footprint is >= 64 px wide (LOD <= 0, mag filter linear,
+     * src/topsy/sph.py:425-426), else the NEAREST texel of the mip the rounded LOD selects (min / mipmap filters
+     * left at wgpu's default).  The two alternatives below are what a driver with other filter defaults would
+     * do; they exist to diagnose such differences and run on the generic kernel only. */
+    TSP_SAMPLE_BILINEAR_MIP0 = 0x10,  /* bilinear on mip 0 whatever the footprint width */
+    TSP_SAMPLE_BILINEAR_MIP = 0x20    /* bilinear within the mip the rounded LOD selects */
 };
 
 const char *tsp_last_error(void);

@@ -82,43 +82,51 @@ typedef struct {
     float f;
 } axis_t;
 
-static inline axis_t axis_bilinear(float u) {
+static inline axis_t axis_bilinear_n(float u, int n) {
     axis_t a;
-    float tu = u * 64.0f - 0.5f;
+    float tu = u * (float)n - 0.5f;
     float x0 = floorf(tu);
     a.f = tu - x0;
-    a.i0 = clampi((int)x0, 0, 63);
-    a.i1 = clampi((int)x0 + 1, 0, 63);
+    a.i0 = clampi((int)x0, 0, n - 1);
+    a.i1 = clampi((int)x0 + 1, 0, n - 1);
     return a;
 }
+static inline axis_t axis_bilinear(float u) { return axis_bilinear_n(u, 64); }
 
 static inline int axis_nearest(float u, int n) { return clampi((int)floorf(u * (float)n), 0, n - 1); }
 
 /* Splat one particle into acc (R*R*C doubles).  nch = 2 (w[0]=m/h^2, w[1]=q), 4 = rgb + count. */
-static void splat_one(double *acc, int R, int C, const float *mips, proj_t pr, const float *w, long *nfrag) {
+/* Sampling rule.  0 = "O1", the rule that reproduces all of the reference's golden
+ * vectors: bilinear on mip 0 when P >= 64, else the NEAREST texel of the mip chosen by the rounded LOD.
+ * The two alternatives are kept for diagnosis against other WebGPU drivers: 1 = bilinear on mip 0 always,
+ * 2 = bilinear within the chosen mip. */
+static void splat_one(double *acc, int R, int C, const float *mips, proj_t pr, const float *w, long *nfrag, int rule) {
     int ilo, ihi, jlo, jhi;
     cand(pr.pcx, pr.half, R, &ilo, &ihi);
     cand(pr.pcy, pr.half, R, &jlo, &jhi);
     if (ihi < ilo || jhi < jlo) return;
     int lvl = level_for(pr.P);
+    int bn = 64, boff = 0;                  /* mip sampled bilinearly when lvl < 0 */
+    if (rule == 1) lvl = -1;
+    else if (rule == 2 && lvl >= 0) { bn = MIP_N[lvl]; boff = MIP_OFF[lvl]; lvl = -1; }
     for (int j = jlo; j <= jhi; ++j) {
         float dy = ((float)j + 0.5f) - pr.pcy;
         if (!(fabsf(dy) < pr.half)) continue;
         float v = (dy + pr.half) * pr.invP;
         axis_t ay = {0, 0, 0.f};
         int ty = 0;
-        if (lvl < 0) ay = axis_bilinear(v); else ty = axis_nearest(v, MIP_N[lvl]);
+        if (lvl < 0) ay = axis_bilinear_n(v, bn); else ty = axis_nearest(v, MIP_N[lvl]);
         for (int i = ilo; i <= ihi; ++i) {
             float dx = ((float)i + 0.5f) - pr.pcx;
             if (!(fabsf(dx) < pr.half)) continue;
             float u = (dx + pr.half) * pr.invP;
             float k;
             if (lvl < 0) {
-                axis_t ax = axis_bilinear(u);
-                const float *T = mips;
+                axis_t ax = axis_bilinear_n(u, bn);
+                const float *T = mips + boff;
                 float gx = 1.0f - ax.f, gy = 1.0f - ay.f;
-                float top = T[ay.i0 * 64 + ax.i0] * gx + T[ay.i0 * 64 + ax.i1] * ax.f;
-                float bot = T[ay.i1 * 64 + ax.i0] * gx + T[ay.i1 * 64 + ax.i1] * ax.f;
+                float top = T[ay.i0 * bn + ax.i0] * gx + T[ay.i0 * bn + ax.i1] * ax.f;
+                float bot = T[ay.i1 * bn + ax.i0] * gx + T[ay.i1 * bn + ax.i1] * ax.f;
                 k = top * gy + bot * ay.f;
             } else {
                 int n = MIP_N[lvl];
@@ -144,11 +152,11 @@ static void splat_one(double *acc, int R, int C, const float *mips, proj_t pr, c
  * a,b,c: mode 0: a=mass, b=qty (may be NULL -> 0), c unused; mode 1: a=mass; mode 2: a,b,c = r,g,b.
  * starts/lens: particle index ranges (NULL -> all).  out: R*R*C float32 (C = 2 or 4).
  * accumulate != 0 adds to `out` instead of overwriting.  Returns total fragment count. */
-long orc_splat(long n, const float *x, const float *y, const float *z, const float *h,
-               const float *a, const float *b, const float *c, int mode,
-               const float *M, float sf, int R, const float *mips,
-               const int64_t *starts, const int64_t *lens, int nranges,
-               int accumulate, int nthreads, float *out) {
+long orc_splat_rule(long n, const float *x, const float *y, const float *z, const float *h,
+                    const float *a, const float *b, const float *c, int mode,
+                    const float *M, float sf, int R, const float *mips,
+                    const int64_t *starts, const int64_t *lens, int nranges,
+                    int accumulate, int nthreads, float *out, int rule) {
     const int C = (mode == 2) ? 4 : 2;
     const size_t npx = (size_t)R * R * C;
     int64_t s0 = 0, l0 = n;
@@ -187,7 +195,7 @@ long orc_splat(long n, const float *x, const float *y, const float *z, const flo
                     w[0] = a[p] / hh;
                     w[1] = (mode == 1) ? pr.cz : (b ? b[p] : 0.0f);
                 }
-                splat_one(acc, R, C, mips, pr, w, &nf);
+                splat_one(acc, R, C, mips, pr, w, &nf, rule);
             }
         }
         total_frag += nf;
@@ -203,6 +211,15 @@ long orc_splat(long n, const float *x, const float *y, const float *z, const flo
     for (int t = 0; t < nthreads; ++t) free(accs[t]);
     free(accs);
     return total_frag;
+}
+
+/* the reference's sampling (rule "O1") */
+long orc_splat(long n, const float *x, const float *y, const float *z, const float *h,
+               const float *a, const float *b, const float *c, int mode,
+               const float *M, float sf, int R, const float *mips,
+               const int64_t *starts, const int64_t *lens, int nranges,
+               int accumulate, int nthreads, float *out) {
+    return orc_splat_rule(n, x, y, z, h, a, b, c, mode, M, sf, R, mips, starts, lens, nranges, accumulate, nthreads, out, 0);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -29,6 +29,8 @@ def lib():
         L.orc_splat.argtypes = [ctypes.c_long, _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                 _fp, ctypes.c_float, ctypes.c_int, _fp, _ip, _ip, ctypes.c_int,
                                 ctypes.c_int, ctypes.c_int, _fp]
+        L.orc_splat_rule.restype = ctypes.c_long
+        L.orc_splat_rule.argtypes = L.orc_splat.argtypes + [ctypes.c_int]
         L.orc_colormap_scalar.restype = None
         L.orc_colormap_scalar.argtypes = [_fp, ctypes.c_long, ctypes.c_int, _fp, ctypes.c_int,
                                           ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _bp]
@@ -57,7 +59,7 @@ def _f(a):
 
 
 def splat(x, y, z, h, a, b=None, c=None, *, mode=0, M, sf, R, mips, ranges=None, out=None,
-          nthreads=0):
+          nthreads=0, sampling=0):
     """mode 0: a=mass, b=qty|None; mode 1 (depth): a=mass; mode 2 (rgb): a,b,c=r,g,b.
     Returns ((R,R,C) float32 image, fragment count)."""
     L = lib()
@@ -79,8 +81,8 @@ def splat(x, y, z, h, a, b=None, c=None, *, mode=0, M, sf, R, mips, ranges=None,
         s = np.ascontiguousarray(ranges[0], dtype=np.int64)
         l = np.ascontiguousarray(ranges[1], dtype=np.int64)
         sp, lp, nr = s.ctypes.data_as(_ip), l.ctypes.data_as(_ip), len(s)
-    nfrag = L.orc_splat(n, *[k[1] for k in keep], mode, Mp, ctypes.c_float(sf), R, mp, sp, lp, nr,
-                        accumulate, nthreads, out.ctypes.data_as(_fp))
+    nfrag = L.orc_splat_rule(n, *[k[1] for k in keep], mode, Mp, ctypes.c_float(sf), R, mp, sp, lp, nr,
+                             accumulate, nthreads, out.ctypes.data_as(_fp), int(sampling))
     return out, nfrag
 
 

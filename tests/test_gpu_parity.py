@@ -366,3 +366,27 @@ def test_scattered_small_footprints_leave_the_window(native, mips, mode):
     assert st["n_huge"] == 0 and st["n_mid"] > n // 4 and st["n_small"] > 0          # all are "small" by width
     assert st["n_small"] + st["n_mid"] + st["n_culled"] == n
     ctx.close()
+
+
+@pytest.mark.parametrize("rule", [1, 2], ids=["bilinear_mip0", "bilinear_mip"])
+def test_alternative_sampling_rules(native, mips, rule):
+    """TSP_SAMPLE_BILINEAR_MIP0 / _MIP (diagnostic, generic kernel): same restatement as the oracle's `sampling`
+    argument, and really different from the reference rule."""
+    from oracle import oracle_np, oracle_c
+    R = 256
+    M, sf = oracle_np.transform_matrix(_rot(0.25, -0.1), np.zeros(3), 120.0)
+    pos, h, m, q, _ = make_cloud(6000, seed=13)
+    x, y, z = (np.ascontiguousarray(pos[:, k]) for k in range(3))
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(x, y, z, h, m)
+    ctx.upload_quantity(q)
+    flag = native.SAMPLE_BILINEAR_MIP0 if rule == 1 else native.SAMPLE_BILINEAR_MIP
+    ctx.render(M, sf, flags=flag)                     # implies the generic kernel
+    got = ctx.read_image()
+    want, _ = oracle_c.splat(x, y, z, h, m, q, mode=0, M=M, sf=sf, R=R, mips=mips, sampling=rule)
+    terms, _ = oracle_c.splat(x, y, z, h, m, np.abs(q), mode=0, M=M, sf=sf, R=R, mips=mips, sampling=rule)
+    check_2ch(got, want, terms[..., 1])
+    ref, _ = oracle_c.splat(x, y, z, h, m, q, mode=0, M=M, sf=sf, R=R, mips=mips)
+    assert np.abs(want[..., 0] / np.maximum(ref[..., 0], 1e-30) - 1.0).max() > 1e-3
+    ctx.close()

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libtopsy_splat.so")
 
 MODE_WEIGHTED, MODE_DEPTH, MODE_RGB = 0, 1, 2
 PIPE_DEFAULT, PIPE_GENERIC = 0, 1
+SAMPLE_BILINEAR_MIP0, SAMPLE_BILINEAR_MIP = 0x10, 0x20      # diagnostic sampling rules (generic kernel)
 UNIQUE_ID_BYTES = 128
 
 

@@ -325,7 +325,8 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
     ctx->stats.n_particles = total;
     int rc = TSP_OK;
     if (total > 0) {
-        if (flags & TSP_PIPE_GENERIC) {
+        const int rule = (flags & TSP_SAMPLE_BILINEAR_MIP0) ? 1 : ((flags & TSP_SAMPLE_BILINEAR_MIP) ? 2 : 0);
+        if ((flags & TSP_PIPE_GENERIC) || rule != 0) {     // the alternative sampling rules exist in the generic kernel only
             // device copy of the ranges: starts | lens | prefix
             std::vector<int64_t> pack(3 * (size_t)nr + 1);
             int64_t acc = 0;
@@ -343,7 +344,7 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
             }
             TSP_HIP(hipMemcpyAsync(ctx->ws.range_prefix, pack.data(), pack.size() * sizeof(int64_t),
                                    hipMemcpyHostToDevice, ctx->stream));
-            rc = launch_generic(ctx, cam, ctx->ws.range_prefix, nr, total, mode);
+            rc = launch_generic(ctx, cam, ctx->ws.range_prefix, nr, total, mode, rule);
             // pack must outlive the async copy
             TSP_HIP(hipStreamSynchronize(ctx->stream));
         } else {

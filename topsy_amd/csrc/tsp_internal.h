@@ -114,7 +114,7 @@ struct tsp_context {
 namespace tsp {
 // kernels / launchers implemented in the other translation units
 int launch_generic(tsp_context *ctx, const Camera &cam, const int64_t *d_ranges, int n_ranges,
-                   int64_t total, int mode);
+                   int64_t total, int mode, int rule);
 int launch_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_starts, const int64_t *h_lens,
                     int n_ranges, int64_t total, int mode);
 int launch_colormap_scalar(tsp_context *ctx, const float *d_img, int64_t npix, int C, const float *d_lut,

@@ -119,6 +119,24 @@ __device__ __forceinline__ float sample_kernel(const LUT &T, const Proj &p, int 
     return T[mip_offset(lvl) + nearest_index(v, n) * n + nearest_index(u, n)];
 }
 
+// The same with a selectable sampling rule (TSP_SAMPLE_*): 0 = "O1" as above; 1 = bilinear on
+// mip 0 whatever the footprint width; 2 = bilinear within the mip the rounded LOD selects.  Diagnostic only.
+template <typename LUT>
+__device__ __forceinline__ float sample_kernel_rule(const LUT &T, const Proj &p, float dx, float dy, int rule) {
+    int lvl = level_for(p.P);
+    if (rule == 0 || (rule != 1 && lvl < 0)) return sample_kernel(T, p, lvl, dx, dy);
+    if (rule == 1) return sample_kernel(T, p, -1, dx, dy);
+    const int n = 64 >> lvl, off = mip_offset(lvl);
+    const float tu = ((dx + p.half) * p.invP) * (float)n - 0.5f, tv = ((dy + p.half) * p.invP) * (float)n - 0.5f;
+    const float x0 = __builtin_floorf(tu), y0 = __builtin_floorf(tv);
+    const float fx = tu - x0, fy = tv - y0, gx = 1.0f - fx, gy = 1.0f - fy;
+    const int ix0 = clampi((int)x0, 0, n - 1), ix1 = clampi((int)x0 + 1, 0, n - 1);
+    const int iy0 = clampi((int)y0, 0, n - 1), iy1 = clampi((int)y0 + 1, 0, n - 1);
+    const float top = T[off + iy0 * n + ix0] * gx + T[off + iy0 * n + ix1] * fx;
+    const float bot = T[off + iy1 * n + ix0] * gx + T[off + iy1 * n + ix1] * fx;
+    return top * gy + bot * fy;
+}
+
 // ------------------------------------------------------------------------------------------
 // canonical float32 log / exp / pow (colormap).  WGSL leaves log()/pow() precision
 // implementation-defined; the path fixes one algorithm so the uint8 image is reproducible.

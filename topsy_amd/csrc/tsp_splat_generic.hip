@@ -31,7 +31,7 @@ __device__ __forceinline__ int64_t work_to_particle(const int64_t *ranges, int n
 template <int MODE>
 __global__ __launch_bounds__(256) void splat_generic_kernel(Particles p, const int64_t *ranges, int n_ranges,
                                                             int64_t total, Camera cam, const float *mips_g,
-                                                            double *img, Counters *cnt, int count_frag) {
+                                                            double *img, Counters *cnt, int count_frag, int rule) {
     __shared__ float T[MIP_TOTAL];
     for (int i = threadIdx.x; i < MIP_TOTAL; i += 256) T[i] = mips_g[i];
     __syncthreads();
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void splat_generic_kernel(Particles p, const i
                 const float dy = ((float)j + 0.5f) - pr.pcy;
                 for (int i = ilo; i <= ihi; ++i) {
                     const float dx = ((float)i + 0.5f) - pr.pcx;
-                    const float k = sample_kernel(T, pr, lvl, dx, dy);
+                    const float k = rule ? sample_kernel_rule(T, pr, dx, dy, rule) : sample_kernel(T, pr, lvl, dx, dy);
                     double *px = img + ((size_t)j * R + i) * C;
                     if (MODE == TSP_MODE_RGB) {
                         atomic_add_f32(px + 0, k * w0);
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void splat_generic_kernel(Particles p, const i
                 const int j = bj + jj, i = bi + (idx - jj * bnx);
                 const float dy = ((float)j + 0.5f) - q.pcy;
                 const float dx = ((float)i + 0.5f) - q.pcx;
-                const float k = sample_kernel(T, q, blvl, dx, dy);
+                const float k = rule ? sample_kernel_rule(T, q, dx, dy, rule) : sample_kernel(T, q, blvl, dx, dy);
                 double *px = img + ((size_t)j * R + i) * C;
                 if (MODE == TSP_MODE_RGB) {
                     atomic_add_f32(px + 0, k * a0);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void splat_generic_kernel(Particles p, const i
 }
 
 int launch_generic(tsp_context *ctx, const Camera &cam, const int64_t *d_ranges, int n_ranges, int64_t total,
-                   int mode) {
+                   int mode, int rule) {
     if (total <= 0) return TSP_OK;
     int64_t blocks = (total + 255) / 256;
     const int64_t cap = (int64_t)ctx->cu_count * 8;
@@ -144,15 +144,15 @@ int launch_generic(tsp_context *ctx, const Camera &cam, const int64_t *d_ranges,
     switch (mode) {
         case TSP_MODE_WEIGHTED:
             hipLaunchKernelGGL(splat_generic_kernel<TSP_MODE_WEIGHTED>, grid, block, 0, ctx->stream, parts, d_ranges,
-                               n_ranges, total, cam, ctx->mips, ctx->image64, ctx->counters, cf);
+                               n_ranges, total, cam, ctx->mips, ctx->image64, ctx->counters, cf, rule);
             break;
         case TSP_MODE_DEPTH:
             hipLaunchKernelGGL(splat_generic_kernel<TSP_MODE_DEPTH>, grid, block, 0, ctx->stream, parts, d_ranges,
-                               n_ranges, total, cam, ctx->mips, ctx->image64, ctx->counters, cf);
+                               n_ranges, total, cam, ctx->mips, ctx->image64, ctx->counters, cf, rule);
             break;
         case TSP_MODE_RGB:
             hipLaunchKernelGGL(splat_generic_kernel<TSP_MODE_RGB>, grid, block, 0, ctx->stream, parts, d_ranges,
-                               n_ranges, total, cam, ctx->mips, ctx->image64, ctx->counters, cf);
+                               n_ranges, total, cam, ctx->mips, ctx->image64, ctx->counters, cf, rule);
             break;
         default:
             set_error("bad mode %d", mode);
