@@ -204,71 +204,69 @@ int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm
     Particles &p = ctx->p;
     const int64_t n = p.n;
     hipStream_t st = ctx->stream;
-    unsigned *mm = nullptr;
-    TSP_HIP(hipMalloc((void **)&mm, 6 * sizeof(unsigned)));
-    const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0};
-    TSP_HIP(hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(bbox_kernel, dim3(1024), dim3(256), 0, st, p.x, p.y, p.z, n, mm);
-    unsigned hmm[6];
-    TSP_HIP(hipMemcpyAsync(hmm, mm, sizeof(hmm), hipMemcpyDeviceToHost, st));
-    TSP_HIP(hipStreamSynchronize(st));
-    TSP_HIP(hipFree(mm));
     float lo[3], inv[3];
-    for (int k = 0; k < 3; ++k) {
-        const float a = unordered_f32(hmm[k]), b = unordered_f32(hmm[3 + k]);
-        lo[k] = a;
-        inv[k] = (b > a) ? 65535.0f / (b - a) : 0.0f;
+    {   // bounding box of the positions
+        DeviceScratch mm;
+        TSP_HIP(mm.alloc(6 * sizeof(unsigned)));
+        const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0, 0, 0};
+        TSP_HIP(hipMemcpyAsync(mm.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(bbox_kernel, dim3(1024), dim3(256), 0, st, p.x, p.y, p.z, n, mm.as<unsigned>());
+        unsigned hmm[6];
+        TSP_HIP(hipMemcpyAsync(hmm, mm.p, sizeof(hmm), hipMemcpyDeviceToHost, st));
+        TSP_HIP(hipStreamSynchronize(st));
+        for (int k = 0; k < 3; ++k) {
+            const float a = unordered_f32(hmm[k]), b = unordered_f32(hmm[3 + k]);
+            lo[k] = a;
+            inv[k] = (b > a) ? 65535.0f / (b - a) : 0.0f;
+        }
     }
-    uint64_t *keys = nullptr, *keys2 = nullptr;
-    uint32_t *vals = nullptr, *vals2 = nullptr;
-    TSP_HIP(hipMalloc((void **)&keys, (size_t)n * 8));
-    TSP_HIP(hipMalloc((void **)&keys2, (size_t)n * 8));
-    TSP_HIP(hipMalloc((void **)&vals, (size_t)n * 4));
-    TSP_HIP(hipMalloc((void **)&vals2, (size_t)n * 4));
-    hipLaunchKernelGGL(morton_key_kernel, dim3(4096), dim3(256), 0, st, p.x, p.y, p.z, n,
-                       make_float3(lo[0], lo[1], lo[2]), make_float3(inv[0], inv[1], inv[2]), n_strata, seed, keys, vals);
-    TSP_HIP(hipGetLastError());
-    size_t tmp_bytes = 0;
-    TSP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, n, 0, 60, st));
-    void *tmp = nullptr;
-    TSP_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-    TSP_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, n, 0, 60, st));
-    {   // stratum boundaries in the new order (keys2 holds the sorted keys)
-        int64_t *d_off = nullptr;
-        TSP_HIP(hipMalloc((void **)&d_off, (size_t)(n_strata + 1) * sizeof(int64_t)));
-        hipLaunchKernelGGL(strata_offsets_kernel, dim3((n_strata + 256) / 256), dim3(256), 0, st, keys2, n, n_strata, d_off);
+    DeviceScratch order;       // order[new] = old index (relative to the current order)
+    {
+        DeviceScratch keys, keys2, vals, tmp;
+        TSP_HIP(keys.alloc((size_t)n * 8));
+        TSP_HIP(keys2.alloc((size_t)n * 8));
+        TSP_HIP(vals.alloc((size_t)n * 4));
+        TSP_HIP(order.alloc((size_t)n * 4));
+        hipLaunchKernelGGL(morton_key_kernel, dim3(4096), dim3(256), 0, st, p.x, p.y, p.z, n,
+                           make_float3(lo[0], lo[1], lo[2]), make_float3(inv[0], inv[1], inv[2]), n_strata, seed,
+                           keys.as<uint64_t>(), vals.as<uint32_t>());
+        TSP_HIP(hipGetLastError());
+        size_t tmp_bytes = 0;
+        TSP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(),
+                                                   vals.as<uint32_t>(), order.as<uint32_t>(), n, 0, 60, st));
+        TSP_HIP(tmp.alloc(tmp_bytes));
+        TSP_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tmp_bytes, keys.as<uint64_t>(), keys2.as<uint64_t>(),
+                                                   vals.as<uint32_t>(), order.as<uint32_t>(), n, 0, 60, st));
+        // stratum boundaries in the new order (keys2 holds the sorted keys)
+        DeviceScratch d_off;
+        TSP_HIP(d_off.alloc((size_t)(n_strata + 1) * sizeof(int64_t)));
+        hipLaunchKernelGGL(strata_offsets_kernel, dim3((n_strata + 256) / 256), dim3(256), 0, st, keys2.as<uint64_t>(), n,
+                           n_strata, d_off.as<int64_t>());
         TSP_HIP(hipGetLastError());
         ctx->strata_offsets.assign((size_t)n_strata + 1, 0);
-        TSP_HIP(hipMemcpyAsync(ctx->strata_offsets.data(), d_off, (size_t)(n_strata + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        TSP_HIP(hipMemcpyAsync(ctx->strata_offsets.data(), d_off.p, (size_t)(n_strata + 1) * sizeof(int64_t),
+                               hipMemcpyDeviceToHost, st));
         TSP_HIP(hipStreamSynchronize(st));
-        TSP_HIP(hipFree(d_off));
     }
-    TSP_HIP(hipStreamSynchronize(st));
-    TSP_HIP(hipFree(tmp));
-    TSP_HIP(hipFree(keys));
-    TSP_HIP(hipFree(keys2));
-    TSP_HIP(hipFree(vals));
-    // vals2[new] = old index (relative to the current order)
-    float *buf = nullptr;
-    TSP_HIP(hipMalloc((void **)&buf, (size_t)n * 4));
+    // permute every resident attribute through one spare buffer
+    DeviceScratch spare;
+    TSP_HIP(spare.alloc((size_t)n * 4));
     float **arrs[] = {&p.x, &p.y, &p.z, &p.h, &p.m, &p.q, &p.r, &p.g, &p.b};
     for (float **a : arrs) {
         if (!*a) continue;
-        hipLaunchKernelGGL(gather_f32_kernel, dim3(4096), dim3(256), 0, st, *a, vals2, buf, n);
+        hipLaunchKernelGGL(gather_f32_kernel, dim3(4096), dim3(256), 0, st, *a, order.as<uint32_t>(), spare.as<float>(), n);
         TSP_HIP(hipGetLastError());
         TSP_HIP(hipStreamSynchronize(st));
-        float *t = *a; *a = buf; buf = t;
+        float *t = *a; *a = spare.as<float>(); spare.p = t;
     }
-    if (p.perm) {   // compose with an earlier reordering: perm_new[i] = perm_old[vals2[i]]
-        hipLaunchKernelGGL(gather_u32_kernel, dim3(4096), dim3(256), 0, st, p.perm, vals2, (uint32_t *)buf, n);
+    if (p.perm) {   // compose with an earlier reordering: perm_new[i] = perm_old[order[i]]
+        hipLaunchKernelGGL(gather_u32_kernel, dim3(4096), dim3(256), 0, st, p.perm, order.as<uint32_t>(), spare.as<uint32_t>(), n);
         TSP_HIP(hipGetLastError());
         TSP_HIP(hipStreamSynchronize(st));
-        uint32_t *t = p.perm; p.perm = (uint32_t *)buf; buf = (float *)t;
-        TSP_HIP(hipFree(vals2));
+        uint32_t *t = p.perm; p.perm = spare.as<uint32_t>(); spare.p = t;
     } else {
-        p.perm = vals2;
+        p.perm = static_cast<uint32_t *>(order.release());
     }
-    TSP_HIP(hipFree(buf));
     if (perm_out) {
         std::vector<uint32_t> hp((size_t)n);
         TSP_HIP(hipMemcpy(hp.data(), p.perm, (size_t)n * 4, hipMemcpyDeviceToHost));
@@ -363,10 +361,11 @@ __global__ __launch_bounds__(256) void read_sum_kernel(const float4 *__restrict_
 int measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, double *gbps_out) {
     bytes &= ~(int64_t)4095;
     if (bytes < 4096) bytes = 4096;
-    float4 *buf = nullptr;
-    float *sink = nullptr;
-    TSP_HIP(hipMalloc((void **)&buf, (size_t)bytes));
-    TSP_HIP(hipMalloc((void **)&sink, 4));
+    DeviceScratch buf_s, sink_s;
+    TSP_HIP(buf_s.alloc((size_t)bytes));
+    TSP_HIP(sink_s.alloc(4));
+    float4 *buf = buf_s.as<float4>();
+    float *sink = sink_s.as<float>();
     TSP_HIP(hipMemsetAsync(buf, 0x11, (size_t)bytes, ctx->stream));
     const unsigned grid = (unsigned)ctx->cu_count * 8;
     hipLaunchKernelGGL(read_sum_kernel, dim3(grid), dim3(256), 0, ctx->stream, buf, bytes / 16, sink);
@@ -378,8 +377,6 @@ int measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, double *g
     float ms = 0.f;
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
     *gbps_out = (double)bytes * iters / (ms * 1e-3) / 1e9;
-    TSP_HIP(hipFree(buf));
-    TSP_HIP(hipFree(sink));
     return TSP_OK;
 }
 

@@ -99,6 +99,7 @@ struct tsp_context {
     int64_t sort_capacity = 0, sorted_count = 0;
     tsp_stats stats = {};
     std::vector<int64_t> strata_offsets;   // first index of every stratum of the last reorder_spatial, then n
+    uint32_t kernel_attr_done = 0;   // bit per kernel family whose dynamic-LDS limit was raised on this context's device
     bool count_fragments = false;
     // pipeline tuning (tsp_set_option)
     float p_small = 11.3f;             // footprints narrower than this many pixels are splatted by kernel S
@@ -112,6 +113,19 @@ struct tsp_context {
 };
 
 namespace tsp {
+// hipMalloc'd scratch that is released on every exit path
+struct DeviceScratch {
+    void *p = nullptr;
+    DeviceScratch() = default;
+    DeviceScratch(const DeviceScratch &) = delete;
+    DeviceScratch &operator=(const DeviceScratch &) = delete;
+    ~DeviceScratch() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+    void *release() { void *q = p; p = nullptr; return q; }
+    void reset(void *q) { if (p) (void)hipFree(p); p = q; }
+};
+
 // kernels / launchers implemented in the other translation units
 int launch_generic(tsp_context *ctx, const Camera &cam, const int64_t *d_ranges, int n_ranges,
                    int64_t total, int mode, int rule);

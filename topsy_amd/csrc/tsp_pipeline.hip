@@ -774,11 +774,11 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
 
 template <int MODE, int NACC, int PXH>
 static int launch_huge(tsp_context *ctx, TileArgs ta, size_t smem_h, long long n_huge) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    const uint32_t attr_bit = 1u << (3 + MODE * 3 + (NACC - 1));
+    if (!(ctx->kernel_attr_done & attr_bit)) {
         TSP_HIP(hipFuncSetAttribute((const void *)splat_huge_kernel<MODE, NACC, PXH>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_h));
-        attr_set = true;
+        ctx->kernel_attr_done |= attr_bit;
     }
     const int htiles_x = (ctx->R + HTILE_W - 1) / HTILE_W, htiles_y = (ctx->R + 16 * PXH - 1) / (16 * PXH);
     const int htiles = htiles_x * htiles_y;
@@ -895,7 +895,6 @@ template <int MODE>
 static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_starts, const int64_t *h_lens, int n_ranges,
                         int64_t total) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
-    constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
     Workspace &ws = ctx->ws;
     hipStream_t st = ctx->stream;
 
@@ -944,7 +943,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
 
     Particles parts = ctx->p;
     if (!ctx->use_quantity) parts.q = nullptr;
-    const int tiles_x = (ctx->R + TILE - 1) / TILE, n_tiles = tiles_x * tiles_x;
+    const int tiles_x = (ctx->R + TILE - 1) / TILE;
     constexpr int WIN = WinSize<MODE>::value;
     const bool second_channel = (MODE == TSP_MODE_DEPTH) || (MODE == TSP_MODE_RGB) || (ctx->p.q != nullptr && ctx->use_quantity);
     const int WCr = (MODE == TSP_MODE_RGB) ? 4 : (second_channel ? 2 : 1);
@@ -953,13 +952,12 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     const size_t smem_m = (size_t)(WCr == 1 ? 1 : WCM) * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float);
     const int mtiles_y = (ctx->R + MTILE_H - 1) / MTILE_H;
     const size_t smem_h = (size_t)(64 * 64 + 512) * sizeof(float4);
-    static bool attr_set[3] = {false, false, false};
-    if (!attr_set[MODE]) {
+    if (!(ctx->kernel_attr_done & (1u << MODE))) {
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WIN * WIN * sizeof(double) + 256)));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WIN * WIN * sizeof(double) + 256)));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, WCM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
-        attr_set[MODE] = true;
+        ctx->kernel_attr_done |= 1u << MODE;
     }
 
     Counters hc, carry;
