@@ -204,7 +204,7 @@ def main():
         # the same positions with footprints capped at 8 px isolate the streaming
         # regime (kernel S only); reported next to the headline, never as `value`
         result["bandwidth_regime"] = hcapped_line(args, ctx, n_total, n_per, rank, M, sf, mode, measured_peak)
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(args, n_total, M, sf, R)
     print(json.dumps(result), flush=True)
     if dist is not None:
