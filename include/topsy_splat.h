@@ -209,9 +209,15 @@ int tsp_measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, doubl
 #define TSP_UNIQUE_ID_BYTES 128
 int tsp_comm_unique_id(char *id_out);
 int tsp_comm_init(tsp_context *ctx, int n_ranks, int rank, const char *id);
-/* Sum-reduce the float32 render target to `root` (or to every rank when root < 0), in place.  Call it
- * once after the frame's last tsp_render: a later tsp_render re-derives the local image from the
- * rank's own float64 accumulator, i.e. the reduced copy is a presentation copy, not an accumulator. */
+/* Sum-reduce the float32 render target to `root` (or to every rank when root < 0), in place.
+ * Contract: every rank calls it exactly ONCE per frame, after the frame's last tsp_render.  The float64
+ * accumulator stays rank-local; the reduced float32 image is a presentation copy (what tsp_read_image,
+ * the colormap calls and autorange see), not an accumulator:
+ *   - a second call without a tsp_render (or tsp_write_image) in between returns TSP_ESTATE instead of
+ *     adding the other ranks' shares twice;
+ *   - any later tsp_render -- including a REFINE block with clear = 0 -- rebuilds the float32 image from
+ *     the rank's own accumulator, so the frame must be reduced again before it is presented.
+ * On ranks other than `root` the image content after the call is unspecified (root >= 0). */
 int tsp_comm_reduce_image(tsp_context *ctx, int root, double *gpu_ms_out);
 int tsp_comm_destroy(tsp_context *ctx);
 

@@ -104,3 +104,23 @@ def test_shard_arithmetic():
             covered[s0 + s:s0 + s + l] += 1
     assert np.array_equal(covered, want)
     assert d.intersect_ranges([5], [10], 100, 50)[0].size == 0
+
+
+def test_sharded_renderer_whole_set_block():
+    """starts = lens = None means the whole snapshot, as in tsp_render: every rank draws exactly its shard."""
+    from topsy_amd import distributed as d
+
+    class FakeContext:
+        def render(self, matrix, scale_factor, starts, lens, clear, mode, flags):
+            self.call = (np.asarray(starts).tolist(), np.asarray(lens).tolist(), clear)
+            return 0.0
+
+    n, g = 1000003, 3
+    drawn = 0
+    for r in range(g):
+        ctx = FakeContext()
+        sr = d.ShardedRenderer(ctx, n, r, g)
+        sr.render_block(np.eye(4), 1.0, None, None, clear=True)
+        assert ctx.call == ([0], [sr.shard_len], True)
+        drawn += sr.shard_len
+    assert drawn == n

@@ -162,10 +162,44 @@ def test_rccl_single_rank_reduce(native, mips):
     ms = ctx.comm_reduce_image(0)
     assert ms >= 0.0
     assert np.array_equal(ctx.read_image(), before)
-    ctx.comm_reduce_image(-1)                          # all-reduce form
-    assert np.array_equal(ctx.read_image(), before)
+    with pytest.raises(native.BackendError, match="already reduced"):
+        ctx.comm_reduce_image(0)                       # one reduce per frame: a repeat would double-count on the root
+    ctx.render(M, sf)                                  # a render rebuilds the local partial image ...
+    ctx.comm_reduce_image(-1)                          # ... which may be reduced again (all-reduce form)
+    assert rel_close(ctx.read_image(), before, 1e-6)   # atomics: the summation order differs between renders
+    ctx.render(M, sf, [0], [50000])
+    ctx.render(M, sf, [50000], [50000], clear=False)   # a REFINE-style block also re-arms the reduce
+    ctx.comm_reduce_image(0)
+    assert np.allclose(ctx.read_image(), before, rtol=1e-6, atol=0)
     with pytest.raises(native.BackendError):
         ctx.comm_init(1, 0, uid)                       # already initialised
+    ctx.close()
+
+
+def test_render_ranges_are_clipped_without_overflow(native, mips):
+    """tsp_render clips (start, len) to [0, n) with saturating arithmetic: a huge len means "to the end", a range
+    that starts before 0 keeps its in-range part, negative lengths are rejected."""
+    ctx = native.Context(96, 2)
+    ctx.set_kernel_mips(mips)
+    n = 50000
+    ctx.generate_synthetic(n, 0, n, 5, 0.0)
+    M, sf = camera(120.0)
+    ctx.render(M, sf)
+    full = ctx.read_image()
+    i64max = np.iinfo(np.int64).max
+    ctx.render(M, sf, [0], [i64max])
+    assert rel_close(ctx.read_image(), full, 1e-6)
+    ctx.render(M, sf, [20000], [i64max])
+    tail = ctx.read_image()
+    ctx.render(M, sf, [20000], [n - 20000])
+    assert rel_close(ctx.read_image(), tail, 1e-6)
+    ctx.render(M, sf, [-5, i64max - 3, n + 7], [20005, i64max, 10])     # [-5, 20000) -> [0, 20000); the others are empty
+    head = ctx.read_image()
+    ctx.render(M, sf, [0], [20000])
+    assert rel_close(ctx.read_image(), head, 1e-6)
+    assert ctx.stats()["n_particles"] == 20000
+    with pytest.raises(native.BackendError, match="negative length"):
+        ctx.render(M, sf, [10], [-1])
     ctx.close()
 
 

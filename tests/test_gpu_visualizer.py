@@ -159,6 +159,44 @@ def test_progressive_frames_fold_mass_scale():
     v.close()
 
 
+def test_depth_query_between_progressive_frames():
+    """A depth query goes through the shared render target (the reference's DepthSPH owns a texture of its own,
+    sph.py:443-446).  The frames after it -- REFINE is the normal next one because _pending_draw stays REFINE after
+    a partial CHANGE frame, and PRESENTATION_CHANGE after a colormap edit -- must redraw the scene instead of
+    adding blocks onto / re-colouring the depth image."""
+    v = topsy_amd.test(200000, render_resolution=128)
+    v.scale = 100.0
+    full = v._sph.get_image().copy()
+    full_rgba = v.draw(DrawReason.EXPORT).copy()
+    rp = v._sph._render_progression
+    rp._recommended_num_particles_to_render = 50000
+    timer = v._sph._render_timer
+    real_add = timer.add_block
+    timer.add_block = lambda ms: real_add(40.0)        # one block per interactive frame
+    v.invalidate()
+    v.draw(DrawReason.CHANGE)
+    assert v._pending_draw == DrawReason.REFINE and v._sph.needs_refine()
+    depth = v.get_depth_image()
+    assert depth.shape == (128, 128)
+    assert v._pending_draw == DrawReason.CHANGE       # the visualizer knows the target was overwritten
+    # even if the caller insists on REFINE, the renderer starts the frame again rather than refining the depth image
+    v.draw(DrawReason.REFINE)
+    for _ in range(64):
+        if not v._sph.needs_refine():
+            break
+        v.draw(DrawReason.REFINE)
+    assert v._sph.last_render_mass_scale == 1.0
+    npt.assert_allclose(v._sph.get_image()[..., 0], full[..., 0], rtol=2e-5, atol=1e-20)
+    # PRESENTATION_CHANGE straight after a depth query re-renders too (it would colour the depth image otherwise)
+    timer.add_block = real_add
+    v._sph.get_depth_image(DrawReason.EXPORT)
+    out = v.draw(DrawReason.PRESENTATION_CHANGE)
+    while v._sph.needs_refine():
+        out = v.draw(DrawReason.REFINE)
+    assert np.abs(out.astype(int) - full_rgba.astype(int)).max() <= 1
+    v.close()
+
+
 @pytest.mark.parametrize("mode", ["density", "weighted-average"])
 @pytest.mark.parametrize("log_scale", [True, False], ids=["log", "linear"])
 def test_colormap_vs_matplotlib(mode, log_scale):  # reference tests/test_colormap.py:35-105

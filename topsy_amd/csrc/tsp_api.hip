@@ -106,6 +106,26 @@ int tsp_device_count(void) {
     return n;
 }
 
+static int create_resources(tsp_context *ctx, int device_id, int resolution, int n_channels) {
+    hipDeviceProp_t prop;
+    TSP_HIP(hipGetDeviceProperties(&prop, device_id));
+    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    TSP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    TSP_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    for (auto &e : ctx->ev) TSP_HIP(hipEventCreate(&e));
+    const size_t npx = (size_t)resolution * resolution;
+    TSP_HIP(hipMalloc((void **)&ctx->image, npx * n_channels * sizeof(float)));
+    TSP_HIP(hipMemsetAsync(ctx->image, 0, npx * n_channels * sizeof(float), ctx->stream));
+    TSP_HIP(hipMalloc((void **)&ctx->image64, npx * n_channels * sizeof(double)));
+    TSP_HIP(hipMemsetAsync(ctx->image64, 0, npx * n_channels * sizeof(double), ctx->stream));
+    TSP_HIP(hipMalloc((void **)&ctx->mips, MIP_TOTAL * sizeof(float)));
+    TSP_HIP(hipMalloc((void **)&ctx->counters, sizeof(Counters)));
+    TSP_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(Counters), ctx->stream));
+    TSP_HIP(hipMalloc((void **)&ctx->out8, npx * 4));
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
 int tsp_create(int device_id, int resolution, int n_channels, tsp_context **out) {
     TSP_REQUIRE(out != nullptr, TSP_EINVAL, "out is NULL");
     *out = nullptr;
@@ -124,22 +144,13 @@ int tsp_create(int device_id, int resolution, int n_channels, tsp_context **out)
     ctx->R = resolution;
     ctx->C = n_channels;
     ctx->Ccap = n_channels;
-    hipDeviceProp_t prop;
-    TSP_HIP(hipGetDeviceProperties(&prop, device_id));
-    ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    TSP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    TSP_HIP(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    for (auto &e : ctx->ev) TSP_HIP(hipEventCreate(&e));
-    const size_t npx = (size_t)resolution * resolution;
-    TSP_HIP(hipMalloc((void **)&ctx->image, npx * n_channels * sizeof(float)));
-    TSP_HIP(hipMemsetAsync(ctx->image, 0, npx * n_channels * sizeof(float), ctx->stream));
-    TSP_HIP(hipMalloc((void **)&ctx->image64, npx * n_channels * sizeof(double)));
-    TSP_HIP(hipMemsetAsync(ctx->image64, 0, npx * n_channels * sizeof(double), ctx->stream));
-    TSP_HIP(hipMalloc((void **)&ctx->mips, MIP_TOTAL * sizeof(float)));
-    TSP_HIP(hipMalloc((void **)&ctx->counters, sizeof(Counters)));
-    TSP_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(Counters), ctx->stream));
-    TSP_HIP(hipMalloc((void **)&ctx->out8, npx * 4));
-    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    // a failed allocation (the float64 master image is R*R*C*8 bytes: 8.6 GB at 16384^2 x 4) must not leak the
+    // streams, events and buffers created before it: tsp_destroy releases whatever exists (the error text stays)
+    const int rc = create_resources(ctx, device_id, resolution, n_channels);
+    if (rc != TSP_OK) {
+        tsp_destroy(ctx);
+        return rc;
+    }
     *out = ctx;
     return TSP_OK;
 }
@@ -300,10 +311,17 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
         if (ctx->p.n > 0) { s.push_back(0); l.push_back(ctx->p.n); }
     } else {
         for (int i = 0; i < n_ranges; ++i) {
-            int64_t b = starts[i], e = starts[i] + lens[i];
-            if (b < 0) b = 0;
-            if (e > ctx->p.n) e = ctx->p.n;
-            if (e > b) { s.push_back(b); l.push_back(e - b); }
+            TSP_REQUIRE(lens[i] >= 0, TSP_EINVAL, "range %d has negative length %lld", i, (long long)lens[i]);
+            // clip without forming starts + lens (a caller may pass INT64_MAX for "to the end")
+            int64_t b = starts[i], len = lens[i];
+            if (b < 0) {
+                len = (len > -b) ? len + b : 0;      // b > INT64_MIN + len, no overflow
+                b = 0;
+            }
+            if (b >= ctx->p.n || len == 0) continue;
+            if (len > ctx->p.n - b) len = ctx->p.n - b;
+            s.push_back(b);
+            l.push_back(len);
         }
     }
     const int nr = (int)s.size();
@@ -353,6 +371,7 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
     }
     if (rc) return rc;
     if ((rc = launch_image_convert(ctx, true))) return rc;     // round the float64 master image once
+    ctx->image_is_reduced = false;                             // `image` is this rank's partial image again
     TSP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     TSP_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
@@ -382,6 +401,7 @@ int tsp_write_image(tsp_context *ctx, const float *in) {
     TSP_HIP(hipMemcpy(ctx->image, in, (size_t)ctx->R * ctx->R * ctx->C * sizeof(float), hipMemcpyHostToDevice));
     int rc = launch_image_convert(ctx, false);                 // keep the master copy consistent
     if (rc) return rc;
+    ctx->image_is_reduced = false;
     TSP_HIP(hipStreamSynchronize(ctx->stream));
     return TSP_OK;
 }
@@ -430,8 +450,10 @@ int tsp_colormap_rgb(tsp_context *ctx, float vmin, float vmax, float gamma, uint
 int tsp_colormap_set_lut2d(tsp_context *ctx, const float *lut_rgba, int n) {
     TSP_REQUIRE(ctx && lut_rgba && n >= 2 && n <= 4096, TSP_EINVAL, "bad 2-D colormap LUT (n=%d)", n);
     TSP_HIP(hipSetDevice(ctx->device));
-    if (ctx->lut2d_n != n) {
-        if (ctx->lut2d) TSP_HIP(hipFree(ctx->lut2d));
+    if (ctx->lut2d_n != n || !ctx->lut2d) {
+        // the size is recorded only once the new allocation exists: a failed hipMalloc leaves "no LUT"
+        ctx->lut2d_n = 0;
+        if (ctx->lut2d) (void)hipFree(ctx->lut2d);
         ctx->lut2d = nullptr;
         TSP_HIP(hipMalloc((void **)&ctx->lut2d, (size_t)n * n * 4 * sizeof(float)));
         ctx->lut2d_n = n;

@@ -99,6 +99,11 @@ int tsp_comm_reduce_image(tsp_context *ctx, int root, double *gpu_ms_out) {
     if (ctx->n_ranks <= 1 && !ctx->comm) return TSP_OK;   // single GPU: the partial image is the image
     TSP_REQUIRE(ctx->comm, TSP_ESTATE, "tsp_comm_init has not been called");
     TSP_REQUIRE(root < ctx->n_ranks, TSP_EINVAL, "root %d out of range", root);
+    // The reduce runs in place on the float32 presentation copy; the float64 accumulator stays local.  Reducing the
+    // same frame twice would add the other ranks' shares twice on the root, so it is refused: render (or
+    // tsp_write_image) first, which rebuilds the local partial image.
+    TSP_REQUIRE(!ctx->image_is_reduced, TSP_ESTATE,
+                "the render target was already reduced for this frame (call tsp_render before reducing again)");
     TSP_HIP(hipSetDevice(ctx->device));
     const size_t count = (size_t)ctx->R * ctx->R * ctx->C;
     TSP_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
@@ -108,6 +113,7 @@ int tsp_comm_reduce_image(tsp_context *ctx, int root, double *gpu_ms_out) {
         TSP_NCCL(g_rccl.Reduce(ctx->image, ctx->image, count, ncclFloat, ncclSum, root, (ncclComm_t)ctx->comm, ctx->stream));
     TSP_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
     TSP_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->image_is_reduced = true;
     float ms = 0.f;
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
     if (gpu_ms_out) *gpu_ms_out = ms;

@@ -110,6 +110,7 @@ struct tsp_context {
     // RCCL
     void *comm = nullptr;
     int n_ranks = 1, rank = 0;
+    bool image_is_reduced = false;    // `image` already holds the cross-rank sum of the current frame (tsp_comm_reduce_image)
 };
 
 namespace tsp {

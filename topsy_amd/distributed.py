@@ -57,10 +57,17 @@ class ShardedRenderer:
         self.shard_start, self.shard_len = shard_range(n_total, rank, world_size)
 
     def render_block(self, matrix, scale_factor, starts, lens, clear, mode=0, flags=0):
+        """Render this rank's share of one block.  starts = lens = None means the whole snapshot (as in tsp_render)."""
+        if starts is None and lens is None:
+            starts, lens = [0], [self.n_total]
         s, l = intersect_ranges(starts, lens, self.shard_start, self.shard_len)
         return self.context.render(matrix, scale_factor, s, l, clear=clear, mode=mode, flags=flags)
 
     def reduce(self, root=0):
+        """Sum the partial images on `root` (every rank when root < 0).  Exactly once per frame, after the frame's
+        last render_block: the library refuses a second reduce of the same frame (it would double-count), and any
+        later render_block -- a REFINE block included -- rebuilds the local partial image, which must then be
+        reduced again before presentation (include/topsy_splat.h, tsp_comm_reduce_image)."""
         if self.world_size > 1:
             return self.context.comm_reduce_image(root)
         return 0.0

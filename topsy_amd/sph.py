@@ -87,7 +87,17 @@ class SPH:
     def _prepare_buffers(self):
         self._visualizer.particle_buffers.ensure_quantity()
 
+    def _target_is_mine(self):
+        """True while the shared device render target still holds THIS renderer's last frame.  SPH, RGBSPH and
+        DepthSPH render into one resident target (the reference gives each its own texture, sph.py:56-63,
+        443-446), so a depth query or another renderer's frame leaves an image that must not be refined,
+        re-coloured or read as this renderer's."""
+        return self.has_rendered and getattr(self._visualizer.particle_buffers, "last_renderer", None) is self
+
     def render(self, draw_reason=DrawReason.CHANGE):
+        if draw_reason in (DrawReason.REFINE, DrawReason.PRESENTATION_CHANGE) and not self._target_is_mine():
+            # nothing of ours to refine / re-present: start the frame again
+            draw_reason = DrawReason.CHANGE
         if draw_reason == DrawReason.PRESENTATION_CHANGE:
             return
         rp = self._render_progression
@@ -121,7 +131,7 @@ class SPH:
 
     def ensure_rendered(self):
         """Trigger an EXPORT-quality render unless this renderer's image is resident (reference sph.py:127-131)."""
-        if not self.has_rendered or getattr(self._visualizer.particle_buffers, "last_renderer", None) is not self:
+        if not self._target_is_mine():
             logger.info("Export-quality render has been triggered, because no valid render is resident.")
             self.render(DrawReason.EXPORT)
 

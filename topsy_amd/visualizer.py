@@ -238,7 +238,10 @@ class VisualizerBase:
         return self._colormap.encode_render_pass(None, None)
 
     def get_depth_image(self):
-        return self._sph.get_depth_image()
+        depth = self._sph.get_depth_image()
+        # the depth pass went through the shared render target: the next frame must redraw the scene
+        self.invalidate(DrawReason.CHANGE)
+        return depth
 
     def save(self, filename="output.npy"):
         self._sph.render(DrawReason.EXPORT)
