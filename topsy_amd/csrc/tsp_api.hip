@@ -601,6 +601,11 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         else ctx->stream_blocks_per_cu = value > 0 ? (int)value : 1;
         return TSP_OK;
     }
+    if (!strcmp(name, "huge_variant")) {
+        TSP_REQUIRE(value >= 0 && value <= 2, TSP_EINVAL, "huge_variant out of range");
+        ctx->huge_variant = (int)value;
+        return TSP_OK;
+    }
     if (!strcmp(name, "overlap_mid_huge")) {
         ctx->overlap_mid_huge = value != 0;
         return TSP_OK;

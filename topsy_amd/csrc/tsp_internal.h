@@ -103,6 +103,7 @@ struct tsp_context {
     bool count_fragments = false;
     // pipeline tuning (tsp_set_option)
     float p_small = 11.3f;             // footprints narrower than this many pixels are splatted by kernel S
+    int huge_variant = 1;             // 0: kernel H (per-pixel gather), 1: kernel H2 64x32 strips, 2: H2 128x16 strips (density)
     int mid_split = 128, huge_split = 0;  // workgroups per image tile (0 = auto)
     int stream_blocks_per_cu = 100;  // kernel S grid bound: ~10 chunks per workgroup at 1e8 particles balances dense and sparse chunks
     bool overlap_mid_huge = false;    // option: kernels M and H on two streams (measured: no gain at 1.25e8, +6 % at 1e7)

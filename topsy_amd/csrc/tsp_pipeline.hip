@@ -795,6 +795,297 @@ static int launch_huge(tsp_context *ctx, TileArgs ta, size_t smem_h, long long n
 }
 
 // ---------------------------------------------------------------------------------------------
+// kernel H2: huge footprints, row-uniform tile gather
+// ---------------------------------------------------------------------------------------------
+// For P >= 64 px a texel of the 64^2 kernel image is >= 1 pixel wide, so along a pixel ROW the y-interpolation
+// factors (fy, gy) and the texel row are the same for every pixel, and along a pixel COLUMN the x-interpolated
+// texel rows  L[r](col) = T[r][c]*gx + T[r][c+1]*fx  change only when the texel row r does -- every P/64 pixels.
+// H2 maps that structure onto the wave: a lane owns W pixel COLUMNS (64 apart) x HR rows in registers, all 64
+// lanes share the same HR pixel rows.  Per footprint a wave
+//   * computes the row factors once, one row per lane (canonical texel coordinate, tsp_math.h), and redistributes
+//     them through a per-wave LDS table so that lane l holds (fy, gy) of rows 4k + (l & 3), k = 0 .. HR/4 - 1:
+//     every QUAD of lanes then carries the four rows of group k and a row's factor reaches all 64 lanes as the
+//     DPP operand of the FMA itself (quad_perm:[t,t,t,t]) -- no LDS read, no scalar register per row;
+//   * walks its rows with WAVE-UNIFORM control flow (bit tests on ballot masks):
+//       on a texel-row change:  top = bot ; bot = L[r + 1](col) from the prefetched pair ; prefetch row r + 2
+//       every covered row:      acc += gy*top ; acc += fy*bot                              -- 2 VALU per pixel
+// against ~14.5 VALU + one 16-byte LDS read per pixel in kernel H.  The sum has the same non-negative terms as the
+// canonical bilinear form in a different association (relative rounding differences of ~1e-7).
+#define TSP_DPP_QUAD(t) "quad_perm:[" #t "," #t "," #t "," #t "] row_mask:0xf bank_mask:0xf"
+
+template <int T> __device__ __forceinline__ void fmac_quad(float &acc, float rowval, float v) {
+    static_assert(T >= 0 && T < 4, "quad lane");
+    if (T == 0) asm volatile("v_fmac_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(0) : "+v"(acc) : "v"(rowval), "v"(v));
+    if (T == 1) asm volatile("v_fmac_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(1) : "+v"(acc) : "v"(rowval), "v"(v));
+    if (T == 2) asm volatile("v_fmac_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(2) : "+v"(acc) : "v"(rowval), "v"(v));
+    if (T == 3) asm volatile("v_fmac_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(3) : "+v"(acc) : "v"(rowval), "v"(v));
+}
+template <int T> __device__ __forceinline__ float mul_quad(float rowval, float v) {
+    float r;
+    if (T == 0) asm volatile("v_mul_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(0) : "=v"(r) : "v"(rowval), "v"(v));
+    if (T == 1) asm volatile("v_mul_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(1) : "=v"(r) : "v"(rowval), "v"(v));
+    if (T == 2) asm volatile("v_mul_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(2) : "=v"(r) : "v"(rowval), "v"(v));
+    if (T == 3) asm volatile("v_mul_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(3) : "=v"(r) : "v"(rowval), "v"(v));
+    return r;
+}
+__device__ __forceinline__ void fmac_plain(float &acc, float x, float y) {     // tied operand: the accumulator stays in place
+    asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(acc) : "v"(x), "v"(y));
+}
+
+constexpr int PT_ROWS = 66;          // pair table rows: 64 + two clamp-to-edge copies of row 63 (for r + 1, r + 2)
+
+constexpr int H2T = 256;             // threads per workgroup of kernel H2: 4 waves = 2 x 2 strips sharing one pair table
+
+template <int MODE, int NACC, int W, int HR>
+__global__ __launch_bounds__(H2T, 4) void splat_huge2_kernel(TileArgs a) {
+    constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
+    constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
+    constexpr int TW = 2 * 64 * W, TH = 2 * HR;            // tile: 2 x 2 wave strips of (64 W) x HR pixels
+    constexpr int NG = HR / 4;                             // row groups (one quad of lanes carries a group's factors)
+    static_assert(HR == 16 || HR == 32, "rows per wave strip");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // pair table: PT[r][c] = (T[r][c], T[r][min(c+1,63)]): one ds_read_b64 fetches both texels of an x-interpolation
+    float2 *PT = reinterpret_cast<float2 *>(smem);                           // [PT_ROWS][64]
+    float2 *rt_all = PT + PT_ROWS * 64;                                      // per wave: (fy, gy) of its HR rows
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int R = a.cam.R;
+    const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
+    const int tx0 = (tile_id % a.tiles_x) * TW, ty0 = (tile_id / a.tiles_x) * TH;
+    for (int i = tid; i < PT_ROWS * 64; i += H2T) {
+        const int j = min(i >> 6, 63), x = i & 63, x1 = min(x + 1, 63);
+        PT[i] = make_float2(a.mips[j * 64 + x], a.mips[j * 64 + x1]);
+    }
+    float2 *rt = rt_all + wv * HR;
+    const float2 *rt_quad = rt + (lane & 3);               // this lane's slot in every row group
+    const int sx = tx0 + 64 * W * (wv & 1), sy = ty0 + HR * (wv >> 1);
+    const float sx0 = (float)sx, sx1 = (float)(sx + 64 * W), sy0 = (float)sy, sy1 = (float)(sy + HR);
+    float pxc[W];
+#pragma unroll
+    for (int w = 0; w < W; ++w) pxc[w] = (sx + 64 * w + lane < R) ? (float)(sx + 64 * w + lane) + 0.5f : __builtin_inff();
+    const int myrow = lane & (HR - 1);
+    const bool rowlane = lane < HR;
+    const float pyc_own = (sy + myrow < R) ? (float)(sy + myrow) + 0.5f : __builtin_inff();
+    const float pyc_prev = pyc_own - 1.0f;                 // centre of the row above (exact; +inf stays +inf)
+
+    // float32 accumulators hold at most FOLD_EVERY footprints (rounding error ~ sqrt(n) * 2^-24 relative: < 2e-6 at
+    // the worst pixel), then go to the float64 render target; second-level register totals (as kernel H keeps) would
+    // cost HR * W more VGPRs and spill here
+    constexpr int FOLD_EVERY = 512;
+    float acc[HR * W][NACC];
+#pragma unroll
+    for (int p = 0; p < HR * W; ++p)
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) acc[p][c] = 0.0f;
+    unsigned long long n_frag = 0;
+    int since_fold = 0;
+    const char *PTb = reinterpret_cast<const char *>(PT);
+    __syncthreads();                                       // the only workgroup barrier: from here on the waves run free
+
+    // Every wave scans the workgroup's share of the record list on its own, 64 records at a time (one per lane),
+    // and keeps those whose square and disc reach ITS strip -- no shared queue, so no wave ever waits for another.
+    // The four waves read the same records at about the same time (L1 / L2 hits).  Records are dealt to the `split`
+    // workgroups of a tile in runs of HDEAL: consecutive records are spatial neighbours (consecutive chunks), so
+    // every workgroup sees an even sample of the tile's footprints.
+    const long long n_runs = (a.n_records + HDEAL - 1) / HDEAL;
+    auto fetch = [&](long long run0, float4 &g, float &gw1, float &gw2) {
+        const long long ri = ((run0 + lane / HDEAL) * a.split + sp) * HDEAL + (lane & (HDEAL - 1));
+        g = make_float4(0.f, 0.f, 0.f, 0.f); gw1 = gw2 = 0.0f;
+        if (ri < a.n_records) {
+            g = a.geom[ri];
+            gw1 = a.w[ri * NW];
+            if (NW == 2) gw2 = a.w[ri * NW + 1];
+        }
+    };
+    float4 g_next; float gw1_next, gw2_next;
+    fetch(0, g_next, gw1_next, gw2_next);
+    for (long long run0 = 0; run0 * a.split < n_runs; run0 += 64 / HDEAL) {
+        const float4 g = g_next;
+        const float gw1 = gw1_next, gw2 = gw2_next;
+        fetch(run0 + 64 / HDEAL, g_next, gw1_next, gw2_next);      // the next 64 records load while these are rasterised
+        const float g_half = 0.5f * g.z;
+        bool hit;
+        {
+            const float sdx = fmaxf(fmaxf(sx0 - g.x, g.x - sx1), 0.0f), sdy = fmaxf(fmaxf(sy0 - g.y, g.y - sy1), 0.0f);
+            // g.z = 0 marks an empty slot; the kernel vanishes outside the disc inscribed in the footprint square
+            hit = g.z > 0.0f && sdx < g_half && sdy < g_half && !(a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * g.z * g.z);
+        }
+        unsigned long long hits = __ballot(hit);
+        if (hits == 0ull) continue;
+        const float g_invP = 1.0f / g.z;
+        const float g_w1 = (MODE == TSP_MODE_RGB) ? gw1 : g.w * gw1;
+        while (hits) {
+            const int src = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            // the footprint's parameters, wave-uniform (scalar registers)
+            const float pcx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.x), src));
+            const float pcy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.y), src));
+            const float half = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_half), src));
+            const float invP = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_invP), src));
+            float4 wq;
+            wq.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.w), src));
+            wq.y = (NACC >= 2) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_w1), src)) : 0.0f;
+            wq.z = (NACC >= 3) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gw2), src)) : 0.0f;
+            wq.w = 0.0f;
+            // ---- rows: lane j < HR evaluates row j and the texel row of the row above it -----------------
+            unsigned covmask, chgmask, jmpmask;
+            int r512;                                   // byte offset of this lane's texel row in PT
+            {
+                const float d = pyc_own - pcy;
+                const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                const float v = (d + half) * invP;
+                const float tv = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, 64.0f, -0.5f), 0.0f, 63.0f);
+                const float f0 = __builtin_floorf(tv);
+                const float fr = (tv - f0) * cv;
+                const int r = (int)f0;
+                const float vp = ((pyc_prev - pcy) + half) * invP;
+                const int rprev = (int)__builtin_floorf(__builtin_amdgcn_fmed3f(__builtin_fmaf(vp, 64.0f, -0.5f), 0.0f, 63.0f));
+                r512 = r * 512;
+                asm volatile("" ::: "memory");          // (in-order LDS: the previous footprint's table reads are done)
+                if (rowlane) rt[myrow] = make_float2(fr, cv - fr);
+                asm volatile("" ::: "memory");
+                const bool covered = rowlane && cv != 0.0f;
+                covmask = (unsigned)__ballot(covered);
+                chgmask = (unsigned)__ballot(covered && myrow > 0 && r != rprev);
+                // texel rows advance by at most one per pixel row when P >= 64; rounding at P ~ 64 may still skip one
+                jmpmask = (unsigned)__ballot(covered && myrow > 0 && r != rprev && r != rprev + 1);
+            }
+            if (covmask == 0u) continue;
+            {   // the first covered row loads both texel rows
+                const unsigned first = covmask & (0u - covmask);
+                chgmask |= first; jmpmask |= first;
+            }
+            // row factors of group k for the DPP broadcast: lane l takes rows 4k + (l & 3)
+            float2 rowf[NG];
+#pragma unroll
+            for (int k = 0; k < NG; ++k) rowf[k] = rt_quad[4 * k];
+            // ---- columns: W per lane ----
+            int caddr[W];
+            float fxs[W], gxs[W];
+            int ncov_x = 0;
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const float d = pxc[w] - pcx;
+                const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                const float u = (d + half) * invP;
+                const float tu = __builtin_amdgcn_fmed3f(__builtin_fmaf(u, 64.0f, -0.5f), 0.0f, 63.0f);
+                const float f0 = __builtin_floorf(tu);
+                const float fr = (tu - f0) * cv;        // uncovered column: both weights 0
+                caddr[w] = ((int)f0) * 8;
+                // density: the particle weight rides on the column factors, so a pixel costs two FMAs
+                fxs[w] = (NACC == 1) ? fr * wq.x : fr;
+                gxs[w] = (NACC == 1) ? (cv - fr) * wq.x : (cv - fr);
+                if (a.count_frag) ncov_x += (cv != 0.0f);
+            }
+            float top[W], bot[W];
+            float2 nxt[W];                              // prefetched pair of texel row r + 2
+            int r_off = 0;                              // byte offset of the current texel row (wave-uniform)
+#pragma unroll
+            for (int w = 0; w < W; ++w) { top[w] = bot[w] = 0.0f; nxt[w] = make_float2(0.f, 0.f); }
+            auto pair_at = [&](int w, int byteoff) -> float2 {
+                return *reinterpret_cast<const float2 *>(PTb + byteoff + caddr[w]);
+            };
+            auto lerp = [&](int w, float2 t) -> float { return __builtin_fmaf(t.y, fxs[w], t.x * gxs[w]); };
+            auto row_change = [&](int ty, bool jump) {      // `jump` is wave-uniform
+                if (jump) {
+                    r_off = __builtin_amdgcn_readlane(r512, ty);
+#pragma unroll
+                    for (int w = 0; w < W; ++w) { top[w] = lerp(w, pair_at(w, r_off)); bot[w] = lerp(w, pair_at(w, r_off + 512)); }
+                } else {
+                    r_off += 512;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) { top[w] = bot[w]; bot[w] = lerp(w, nxt[w]); }
+                }
+#pragma unroll
+                for (int w = 0; w < W; ++w) nxt[w] = pair_at(w, r_off + 1024);
+            };
+#define TSP_H2_ROW(K, T)                                                                                       \
+            {                                                                                                  \
+                constexpr int ty_ = 4 * (K) + (T);                                                             \
+                if ((chgmask >> ty_) & 1u) row_change(ty_, ((jmpmask >> ty_) & 1u) != 0u);                     \
+                _Pragma("unroll") for (int w = 0; w < W; ++w) {                                                \
+                    float *ac = acc[ty_ * W + w];                                                              \
+                    if (NACC == 1) {                                                                           \
+                        fmac_quad<T>(ac[0], rowf[K].y, top[w]);                                                \
+                        fmac_quad<T>(ac[0], rowf[K].x, bot[w]);                                                \
+                    } else {                                                                                   \
+                        float kv = mul_quad<T>(rowf[K].y, top[w]);                                             \
+                        fmac_quad<T>(kv, rowf[K].x, bot[w]);                                                   \
+                        fmac_plain(ac[0], kv, wq.x);                                                           \
+                        fmac_plain(ac[NACC >= 2 ? 1 : 0], kv, wq.y);                                           \
+                        if (NACC >= 3) fmac_plain(ac[NACC - 1], kv, wq.z);                                     \
+                    }                                                                                          \
+                }                                                                                              \
+            }
+            // Only the rolling texel rows (top, bot, nxt) are touched under a branch; the accumulation of a row is
+            // straight-line (an uncovered row has fy = gy = 0), and a group of four rows wholly outside the footprint
+            // is skipped with one test.
+#define TSP_H2_GROUP(K)                                                                                        \
+            if ((K) < NG && ((covmask >> (4 * (K))) & 15u) != 0u) { TSP_H2_ROW(K, 0) TSP_H2_ROW(K, 1) TSP_H2_ROW(K, 2) TSP_H2_ROW(K, 3) }
+            TSP_H2_GROUP(0) TSP_H2_GROUP(1) TSP_H2_GROUP(2) TSP_H2_GROUP(3)
+            TSP_H2_GROUP(4) TSP_H2_GROUP(5) TSP_H2_GROUP(6) TSP_H2_GROUP(7)
+#undef TSP_H2_GROUP
+#undef TSP_H2_ROW
+            if (a.count_frag) n_frag += (unsigned long long)(ncov_x * __popc(covmask));
+            if (++since_fold == FOLD_EVERY) {
+                since_fold = 0;
+#pragma unroll
+                for (int ty = 0; ty < HR; ++ty)
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        const int p = ty * W + w, gx = sx + 64 * w + lane, gy = sy + ty;
+                        if (gx < R && gy < R) {
+                            double *d = a.img + ((size_t)gy * R + gx) * C;
+#pragma unroll
+                            for (int c = 0; c < NACC; ++c) {
+                                if (acc[p][c] != 0.0f) gatomic_add(d + c, acc[p][c]);
+                                acc[p][c] = 0.0f;
+                            }
+                        }
+                    }
+            }
+        }
+    }
+    // ---- add this wave's partial strip into the render target ---------------------------------------
+#pragma unroll
+    for (int ty = 0; ty < HR; ++ty) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const int p = ty * W + w, gx = sx + 64 * w + lane, gy = sy + ty;
+            if (gx < R && gy < R) {
+                double *d = a.img + ((size_t)gy * R + gx) * C;
+#pragma unroll
+                for (int c = 0; c < NACC; ++c) {
+                    const float v = acc[p][c];
+                    if (v != 0.0f) gatomic_add(d + c, v);
+                }
+            }
+        }
+    }
+    if (a.count_frag) {
+        for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
+        if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+    }
+}
+
+template <int MODE, int NACC, int W, int HR>
+static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
+    const size_t smem = (size_t)PT_ROWS * 64 * sizeof(float2) + (H2T / 64) * HR * sizeof(float2);
+    const int tw = 2 * 64 * W, th = 2 * HR;
+    const int htiles_x = (ctx->R + tw - 1) / tw, htiles_y = (ctx->R + th - 1) / th;
+    const int htiles = htiles_x * htiles_y;
+    const long long batches = (n_huge + 63) / 64;
+    int split = ctx->huge_split;
+    if (split <= 0) split = std::max(1, (ctx->cu_count * 32 + htiles - 1) / htiles);
+    split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
+    ta.split = split;
+    ta.tiles_x = htiles_x;
+    hipLaunchKernelGGL((splat_huge2_kernel<MODE, NACC, W, HR>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
+    TSP_HIP(hipGetLastError());
+    return TSP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // rgb fragment-counter channel of the deferred (MID and HUGE) footprints
 // ---------------------------------------------------------------------------------------------
 // fragment_rgb writes (k r, k g, k b, 1): channel 3 counts the footprint SQUARES covering a pixel, also where
@@ -1034,9 +1325,16 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     TSP_HIP(hipEventRecord(ctx->ev[9], st));
     if (hc.n_huge > 0) {
         ta.geom = (const float4 *)ws.huge_geom; ta.w = (const float *)ws.huge_w; ta.n_records = (long long)hc.n_huge;
-        if (MODE == TSP_MODE_RGB) rc = launch_huge<MODE, 3, 4>(ctx, ta, smem_h, (long long)hc.n_huge);
-        else if (second_channel) rc = launch_huge<MODE, 2, 4>(ctx, ta, smem_h, (long long)hc.n_huge);
-        else rc = launch_huge<MODE, 1, 4>(ctx, ta, smem_h, (long long)hc.n_huge);   // 4x8 px/lane measured slower (spills, larger tiles)
+        if (ctx->huge_variant == 0) {           // kernel H (per-pixel bilinear gather), kept for A/B measurements
+            if (MODE == TSP_MODE_RGB) rc = launch_huge<MODE, 3, 4>(ctx, ta, smem_h, (long long)hc.n_huge);
+            else if (second_channel) rc = launch_huge<MODE, 2, 4>(ctx, ta, smem_h, (long long)hc.n_huge);
+            else rc = launch_huge<MODE, 1, 4>(ctx, ta, smem_h, (long long)hc.n_huge);   // 4x8 px/lane measured slower (spills, larger tiles)
+        } else {                                // kernel H2 (row-uniform gather)
+            if (MODE == TSP_MODE_RGB) rc = launch_huge2<MODE, 3, 1, 16>(ctx, ta, (long long)hc.n_huge);
+            else if (second_channel) rc = launch_huge2<MODE, 2, 1, 16>(ctx, ta, (long long)hc.n_huge);
+            else if (ctx->huge_variant == 2) rc = launch_huge2<MODE, 1, 2, 32>(ctx, ta, (long long)hc.n_huge);
+            else rc = launch_huge2<MODE, 1, 1, 32>(ctx, ta, (long long)hc.n_huge);
+        }
         if (rc) return rc;
     }
     if (MODE == TSP_MODE_RGB && (hc.n_mid > 0 || hc.n_huge > 0)) {
