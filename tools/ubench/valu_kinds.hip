@@ -39,6 +39,9 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float s) {
                 else if (OP == 20) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b[i]), "v"(c[i]));
                 else if (OP == 21) asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(a[i]) : "v"(b[i]));
                 else if (OP == 22) asm volatile("v_add_u32_dpp %0, %1, %2 row_ror:12 row_mask:0xf bank_mask:0xf" : "=v"(a[i]) : "v"(b[i]), "v"(c[i]));
+                else if (OP == 23) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "s"(s), "v"(c[i]));
+                else if (OP == 24) { int t; asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(t) : "v"(b[i])); asm volatile("" :: "s"(t)); }
+                else if (OP == 25) asm volatile("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\ts_bitcmp0_b32 %3, 5" : "+v"(a[i]) : "v"(b[i]), "v"(c[i]), "s"(iters) : "scc");
                 else if (OP == 17) asm volatile("v_max_f32 %0, %1, %2" : "=v"(a[i]) : "v"(b[i]), "v"(c[i]));
             }
         }
@@ -76,5 +79,6 @@ int main() {
     run<7>("v_mul_f32 v,v", 1); run<11>("v_mul_f32 s,v", 1); run<8>("v_fmac_f32", 1); run<9>("v_sub_f32", 1); run<16>("v_add_f32", 1); run<17>("v_max_f32", 1);
     run<10>("v_mov_b32", 1);
     run<18>("v_mul_f32_dpp quad_perm", 1); run<19>("v_mul_f32_dpp row_ror:4", 1); run<20>("v_fmac_f32_dpp quad_perm", 1); run<21>("v_mov_b32_dpp row_ror:8", 1); run<22>("v_add_u32_dpp row_ror:12", 1);
+    run<23>("v_fmac_f32 s,v", 1); run<24>("v_readlane_b32", 1); run<25>("v_fmac_dpp + s_bitcmp0 (per pair)", 1);
     return 0;
 }

@@ -381,7 +381,7 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
     TSP_HIP(hipMemcpy(&hc, ctx->counters, sizeof(hc), hipMemcpyDeviceToHost));
     ctx->stats.n_small = (int64_t)hc.n_small;
     ctx->stats.n_mid = (int64_t)hc.n_mid;
-    ctx->stats.n_huge = (int64_t)hc.n_huge;
+    ctx->stats.n_huge = (int64_t)(hc.n_huge + hc.n_mega);
     ctx->stats.n_culled = (int64_t)hc.n_culled;
     ctx->stats.n_fragments = (int64_t)hc.n_fragments;
     if (gpu_ms_out) *gpu_ms_out = ms;
@@ -601,8 +601,13 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         else ctx->stream_blocks_per_cu = value > 0 ? (int)value : 1;
         return TSP_OK;
     }
+    if (!strcmp(name, "p_mega_px")) {         // class boundary H2 / H3 in pixels (>= 64; 0 = no H3)
+        TSP_REQUIRE(value == 0 || (value >= 64 && value <= (1 << 20)), TSP_EINVAL, "p_mega_px out of range");
+        ctx->p_mega = (float)value;
+        return TSP_OK;
+    }
     if (!strcmp(name, "huge_variant")) {
-        TSP_REQUIRE(value >= 0 && value <= 2, TSP_EINVAL, "huge_variant out of range");
+        TSP_REQUIRE(value >= 0 && value <= 8, TSP_EINVAL, "huge_variant out of range");
         ctx->huge_variant = (int)value;
         return TSP_OK;
     }

@@ -50,7 +50,7 @@ struct Record4 {   // rgb variant (24 B)
 };
 
 struct Counters {      // device-side, zeroed per render call
-    unsigned long long n_small, n_mid, n_huge, n_culled, n_fragments, huge_count, pad0, pad1;
+    unsigned long long n_small, n_mid, n_huge, n_culled, n_fragments, huge_count, n_mega, pad1;
 };
 
 struct Workspace {     // per-context scratch of the three-class pipeline (grown on demand)
@@ -103,6 +103,7 @@ struct tsp_context {
     bool count_fragments = false;
     // pipeline tuning (tsp_set_option)
     float p_small = 11.3f;             // footprints narrower than this many pixels are splatted by kernel S
+    float p_mega = 512.0f;            // footprints at least this wide go to kernel H3 (matrix cores); 0 = all to H2
     int huge_variant = 1;             // 0: kernel H (per-pixel gather), 1: kernel H2 64x32 strips, 2: H2 128x16 strips (density)
     int mid_split = 128, huge_split = 0;  // workgroups per image tile (0 = auto)
     int stream_blocks_per_cu = 100;  // kernel S grid bound: ~10 chunks per workgroup at 1e8 particles balances dense and sparse chunks

@@ -43,7 +43,7 @@ constexpr int MSTR = 72;             // LDS row stride (doubles) of the mid tile
 // tools/ubench/lds_partial.hip, lds_atomics.hip), and the sums gain precision.
 template <int MODE> struct WinSize { static constexpr int value = (MODE == TSP_MODE_RGB) ? 48 : 64; };
 
-enum { CLS_NONE = 0, CLS_SMALL = 1, CLS_MID = 2, CLS_HUGE = 3 };
+enum { CLS_NONE = 0, CLS_SMALL = 1, CLS_MID = 2, CLS_HUGE = 3, CLS_MEGA = 4 };
 
 // the render target is accumulated in float64 (global_atomic_add_f64) and rounded to float32 once per
 // tsp_render call, so cross-workgroup summation adds no float32 noise however many flushes hit a pixel
@@ -87,6 +87,7 @@ struct StreamArgs {
     int *seg_count; long long *seg_offset; float4 *seg_bbox;
     Counters *cnt;
     float p_small;
+    float p_mega;              // footprints at least this wide are appended from the END of the huge list (kernel H3's share)
     int count_frag;
     int emit_small;            // 0: records only (replay after a record-list overflow)
 };
@@ -203,8 +204,10 @@ __global__ __launch_bounds__(256, 5) void splat_stream_kernel(StreamArgs a) {
                         cls[k] = CLS_MID; ++my_mid;
                         mx0 = fminf(mx0, pr.pcx - pr.half); mx1 = fmaxf(mx1, pr.pcx + pr.half);
                         my0 = fminf(my0, pr.pcy - pr.half); my1 = fmaxf(my1, pr.pcy + pr.half);
-                    } else {
+                    } else if (pr.P < a.p_mega) {
                         cls[k] = CLS_HUGE; ++my_huge;
+                    } else {
+                        cls[k] = CLS_MEGA;          // rare (~1e-3 of the particles): one atomic each, below
                     }
                 } else {
                     ++n_cull;
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256, 5) void splat_stream_kernel(StreamArgs a) {
         }
 
         // ---- phase 5: append the deferred footprints -----------------------------------------------
-        if (mid_total | huge_total) {
+        {
             long long mpos = mid_base + mid_before + (mid_incl - my_mid);
             long long hpos = huge_base + huge_before + (huge_incl - my_huge);
 #pragma unroll
@@ -333,6 +336,16 @@ __global__ __launch_bounds__(256, 5) void splat_stream_kernel(StreamArgs a) {
                         if (NW == 2) a.huge_w[hpos * NW + 1] = w2[k];
                     }
                     ++hpos;
+                } else if (cls[k] == CLS_MEGA) {
+                    // the mega records grow downwards from the end of the huge list: one allocation, two cursors
+                    // (an overlap with the records growing from the front means overflow: the host sees
+                    // n_huge + n_mega > capacity, enlarges the list and replays)
+                    const long long mp = a.huge_capacity - 1 - (long long)atomicAdd(&a.cnt->n_mega, 1ull);
+                    if (mp >= 0) {
+                        a.huge_geom[mp] = make_float4(pcx[k], pcy[k], PP[k], w0[k]);
+                        a.huge_w[mp * NW] = w1[k];
+                        if (NW == 2) a.huge_w[mp * NW + 1] = w2[k];
+                    }
                 }
             }
         }
@@ -366,6 +379,7 @@ struct TileArgs {
     int tiles_x, split;
     int count_frag;
     float disc_k2;     // (0.5235)^2 when the LUT is zero outside the inscribed disc (exact corner culling), else 0
+    float p_lo, p_hi;  // kernels H2 / H3 take the records with p_lo <= P < p_hi
 };
 
 constexpr int MT = 512;              // threads per workgroup of kernel M (8 waves share tile + LUT)
@@ -832,29 +846,31 @@ __device__ __forceinline__ void fmac_plain(float &acc, float x, float y) {     /
     asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(acc) : "v"(x), "v"(y));
 }
 
-constexpr int PT_ROWS = 66;          // pair table rows: 64 + two clamp-to-edge copies of row 63 (for r + 1, r + 2)
+constexpr int PT_ROWS = 66;          // LDS kernel image rows: 64 + two clamp-to-edge copies of row 63 (for r + 1, r + 2)
+constexpr int PT_STRIDE = 65;        // floats per row: 64 + one clamp-to-edge copy of column 63 (for c + 1); odd -> no bank conflicts
 
 constexpr int H2T = 256;             // threads per workgroup of kernel H2: 4 waves = 2 x 2 strips sharing one pair table
 
-template <int MODE, int NACC, int W, int HR>
-__global__ __launch_bounds__(H2T, 4) void splat_huge2_kernel(TileArgs a) {
+template <int MODE, int NACC, int W, int HR, int OCC>
+__global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
     constexpr int TW = 2 * 64 * W, TH = 2 * HR;            // tile: 2 x 2 wave strips of (64 W) x HR pixels
     constexpr int NG = HR / 4;                             // row groups (one quad of lanes carries a group's factors)
     static_assert(HR == 16 || HR == 32, "rows per wave strip");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // pair table: PT[r][c] = (T[r][c], T[r][min(c+1,63)]): one ds_read_b64 fetches both texels of an x-interpolation
-    float2 *PT = reinterpret_cast<float2 *>(smem);                           // [PT_ROWS][64]
-    float2 *rt_all = PT + PT_ROWS * 64;                                      // per wave: (fy, gy) of its HR rows
+    // level-0 kernel image with clamp-to-edge padding: texels (r, c) and (r, c + 1) of an x-interpolation are adjacent
+    // dwords, fetched by one ds_read2_b32
+    float *PT = smem;                                                        // [PT_ROWS][PT_STRIDE]
+    float2 *rt_all = reinterpret_cast<float2 *>(smem + ((PT_ROWS * PT_STRIDE + 3) & ~3));   // per wave: (fy, gy) of its HR rows
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int R = a.cam.R;
     const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
     const int tx0 = (tile_id % a.tiles_x) * TW, ty0 = (tile_id / a.tiles_x) * TH;
-    for (int i = tid; i < PT_ROWS * 64; i += H2T) {
-        const int j = min(i >> 6, 63), x = i & 63, x1 = min(x + 1, 63);
-        PT[i] = make_float2(a.mips[j * 64 + x], a.mips[j * 64 + x1]);
+    for (int i = tid; i < PT_ROWS * PT_STRIDE; i += H2T) {
+        const int j = min(i / PT_STRIDE, 63), x = min(i % PT_STRIDE, 63);
+        PT[i] = a.mips[j * 64 + x];
     }
     float2 *rt = rt_all + wv * HR;
     const float2 *rt_quad = rt + (lane & 3);               // this lane's slot in every row group
@@ -908,7 +924,7 @@ __global__ __launch_bounds__(H2T, 4) void splat_huge2_kernel(TileArgs a) {
         {
             const float sdx = fmaxf(fmaxf(sx0 - g.x, g.x - sx1), 0.0f), sdy = fmaxf(fmaxf(sy0 - g.y, g.y - sy1), 0.0f);
             // g.z = 0 marks an empty slot; the kernel vanishes outside the disc inscribed in the footprint square
-            hit = g.z > 0.0f && sdx < g_half && sdy < g_half && !(a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * g.z * g.z);
+            hit = g.z > 0.0f && g.z < a.p_hi && sdx < g_half && sdy < g_half && !(a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * g.z * g.z);
         }
         unsigned long long hits = __ballot(hit);
         if (hits == 0ull) continue;
@@ -940,7 +956,7 @@ __global__ __launch_bounds__(H2T, 4) void splat_huge2_kernel(TileArgs a) {
                 const int r = (int)f0;
                 const float vp = ((pyc_prev - pcy) + half) * invP;
                 const int rprev = (int)__builtin_floorf(__builtin_amdgcn_fmed3f(__builtin_fmaf(vp, 64.0f, -0.5f), 0.0f, 63.0f));
-                r512 = r * 512;
+                r512 = r * (PT_STRIDE * 4);
                 asm volatile("" ::: "memory");          // (in-order LDS: the previous footprint's table reads are done)
                 if (rowlane) rt[myrow] = make_float2(fr, cv - fr);
                 asm volatile("" ::: "memory");
@@ -971,7 +987,7 @@ __global__ __launch_bounds__(H2T, 4) void splat_huge2_kernel(TileArgs a) {
                 const float tu = __builtin_amdgcn_fmed3f(__builtin_fmaf(u, 64.0f, -0.5f), 0.0f, 63.0f);
                 const float f0 = __builtin_floorf(tu);
                 const float fr = (tu - f0) * cv;        // uncovered column: both weights 0
-                caddr[w] = ((int)f0) * 8;
+                caddr[w] = ((int)f0) * 4;
                 // density: the particle weight rides on the column factors, so a pixel costs two FMAs
                 fxs[w] = (NACC == 1) ? fr * wq.x : fr;
                 gxs[w] = (NACC == 1) ? (cv - fr) * wq.x : (cv - fr);
@@ -983,26 +999,27 @@ __global__ __launch_bounds__(H2T, 4) void splat_huge2_kernel(TileArgs a) {
 #pragma unroll
             for (int w = 0; w < W; ++w) { top[w] = bot[w] = 0.0f; nxt[w] = make_float2(0.f, 0.f); }
             auto pair_at = [&](int w, int byteoff) -> float2 {
-                return *reinterpret_cast<const float2 *>(PTb + byteoff + caddr[w]);
+                const float *t = reinterpret_cast<const float *>(PTb + byteoff + caddr[w]);
+                return make_float2(t[0], t[1]);
             };
             auto lerp = [&](int w, float2 t) -> float { return __builtin_fmaf(t.y, fxs[w], t.x * gxs[w]); };
             auto row_change = [&](int ty, bool jump) {      // `jump` is wave-uniform
                 if (jump) {
                     r_off = __builtin_amdgcn_readlane(r512, ty);
 #pragma unroll
-                    for (int w = 0; w < W; ++w) { top[w] = lerp(w, pair_at(w, r_off)); bot[w] = lerp(w, pair_at(w, r_off + 512)); }
+                    for (int w = 0; w < W; ++w) { top[w] = lerp(w, pair_at(w, r_off)); bot[w] = lerp(w, pair_at(w, r_off + PT_STRIDE * 4)); }
                 } else {
-                    r_off += 512;
+                    r_off += PT_STRIDE * 4;
 #pragma unroll
                     for (int w = 0; w < W; ++w) { top[w] = bot[w]; bot[w] = lerp(w, nxt[w]); }
                 }
 #pragma unroll
-                for (int w = 0; w < W; ++w) nxt[w] = pair_at(w, r_off + 1024);
+                for (int w = 0; w < W; ++w) nxt[w] = pair_at(w, r_off + 2 * PT_STRIDE * 4);
             };
 #define TSP_H2_ROW(K, T)                                                                                       \
             {                                                                                                  \
                 constexpr int ty_ = 4 * (K) + (T);                                                             \
-                if ((chgmask >> ty_) & 1u) row_change(ty_, ((jmpmask >> ty_) & 1u) != 0u);                     \
+                if ((chgmask >> ty_) & 1u) row_change(ty_, ((jmpmask >> ty_) & 1u) != 0u);                       \
                 _Pragma("unroll") for (int w = 0; w < W; ++w) {                                                \
                     float *ac = acc[ty_ * W + w];                                                              \
                     if (NACC == 1) {                                                                           \
@@ -1017,9 +1034,10 @@ __global__ __launch_bounds__(H2T, 4) void splat_huge2_kernel(TileArgs a) {
                     }                                                                                          \
                 }                                                                                              \
             }
-            // Only the rolling texel rows (top, bot, nxt) are touched under a branch; the accumulation of a row is
-            // straight-line (an uncovered row has fy = gy = 0), and a group of four rows wholly outside the footprint
-            // is skipped with one test.
+            // Only the rolling texel rows (top, bot, nxt) are touched under a (wave-uniform) branch; the accumulation itself
+            // is straight-line (an uncovered row has fy = gy = 0); groups of four rows wholly outside the footprint are
+            // skipped.  (Laying the change out of line as the unlikely path measured slower: this kernel serves the
+            // footprints below p_mega, whose texel rows change every 1-8 pixel rows.)
 #define TSP_H2_GROUP(K)                                                                                        \
             if ((K) < NG && ((covmask >> (4 * (K))) & 15u) != 0u) { TSP_H2_ROW(K, 0) TSP_H2_ROW(K, 1) TSP_H2_ROW(K, 2) TSP_H2_ROW(K, 3) }
             TSP_H2_GROUP(0) TSP_H2_GROUP(1) TSP_H2_GROUP(2) TSP_H2_GROUP(3)
@@ -1029,13 +1047,15 @@ __global__ __launch_bounds__(H2T, 4) void splat_huge2_kernel(TileArgs a) {
             if (a.count_frag) n_frag += (unsigned long long)(ncov_x * __popc(covmask));
             if (++since_fold == FOLD_EVERY) {
                 since_fold = 0;
+                double *img = a.img + ((size_t)sy * R + (sx + lane)) * C;
+                asm volatile("" : "+v"(img));        // addresses are formed here, not hoisted to the kernel entry and spilled
 #pragma unroll
                 for (int ty = 0; ty < HR; ++ty)
 #pragma unroll
                     for (int w = 0; w < W; ++w) {
                         const int p = ty * W + w, gx = sx + 64 * w + lane, gy = sy + ty;
                         if (gx < R && gy < R) {
-                            double *d = a.img + ((size_t)gy * R + gx) * C;
+                            double *d = img + ((size_t)ty * R + 64 * w) * C;
 #pragma unroll
                             for (int c = 0; c < NACC; ++c) {
                                 if (acc[p][c] != 0.0f) gatomic_add(d + c, acc[p][c]);
@@ -1047,13 +1067,15 @@ __global__ __launch_bounds__(H2T, 4) void splat_huge2_kernel(TileArgs a) {
         }
     }
     // ---- add this wave's partial strip into the render target ---------------------------------------
+    double *img_end = a.img + ((size_t)sy * R + (sx + lane)) * C;
+    asm volatile("" : "+v"(img_end));
 #pragma unroll
     for (int ty = 0; ty < HR; ++ty) {
 #pragma unroll
         for (int w = 0; w < W; ++w) {
             const int p = ty * W + w, gx = sx + 64 * w + lane, gy = sy + ty;
             if (gx < R && gy < R) {
-                double *d = a.img + ((size_t)gy * R + gx) * C;
+                double *d = img_end + ((size_t)ty * R + 64 * w) * C;
 #pragma unroll
                 for (int c = 0; c < NACC; ++c) {
                     const float v = acc[p][c];
@@ -1068,9 +1090,9 @@ __global__ __launch_bounds__(H2T, 4) void splat_huge2_kernel(TileArgs a) {
     }
 }
 
-template <int MODE, int NACC, int W, int HR>
+template <int MODE, int NACC, int W, int HR, int OCC>
 static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
-    const size_t smem = (size_t)PT_ROWS * 64 * sizeof(float2) + (H2T / 64) * HR * sizeof(float2);
+    const size_t smem = (size_t)((PT_ROWS * PT_STRIDE + 3) & ~3) * sizeof(float) + (H2T / 64) * HR * sizeof(float2);
     const int tw = 2 * 64 * W, th = 2 * HR;
     const int htiles_x = (ctx->R + tw - 1) / tw, htiles_y = (ctx->R + th - 1) / th;
     const int htiles = htiles_x * htiles_y;
@@ -1080,7 +1102,189 @@ static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
     split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
     ta.split = split;
     ta.tiles_x = htiles_x;
-    hipLaunchKernelGGL((splat_huge2_kernel<MODE, NACC, W, HR>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
+    hipLaunchKernelGGL((splat_huge2_kernel<MODE, NACC, W, HR, OCC>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
+    TSP_HIP(hipGetLastError());
+    return TSP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel H3: mega footprints on the matrix cores
+// ---------------------------------------------------------------------------------------------
+// Within a strip of pixels the contribution of one footprint is a sum of outer products,
+//     img[row][col] += sum_k U[row][k] * V[k][col],   k = the texel rows the strip's pixel rows touch,
+// with V[k][col] = w * (T[r0+k][c]*gx + T[r0+k][c+1]*fx) (x-interpolated texel row) and U[row][k] = gy(row) if row's
+// texel row is r0 + k, fy(row) if it is r0 + k - 1, else 0 -- exactly the shape of v_mfma_f32_32x32x2_f32 (A: 32 rows x
+// 2 k, B: 2 k x 32 columns, one VGPR each, exact f32 FMA chain).  When a texel is >= 8 pixels tall a 32-row strip
+// touches <= 6 texel rows, i.e. <= 3 MFMA k-steps, and the row factors need no broadcast at all: the lane that
+// evaluates row i IS the lane that supplies A[i][k].  The matrix pipe then does the per-pixel work (2 MFMAs per
+// 64x32 strip and k-step) while the VALU only prepares ~80 instructions per footprint and strip.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int MODE, int NACC>
+__global__ __launch_bounds__(H2T, (NACC == 1) ? 4 : (NACC == 2 ? 3 : 2)) void splat_mega_kernel(TileArgs a) {
+    constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
+    constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
+    constexpr int TW = 128, TH = 64;                       // tile: 2 x 2 wave strips of 64 x 32 pixels
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *PT = smem;                                      // [PT_ROWS][PT_STRIDE] level-0 kernel image, clamp-to-edge padded
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;              // MFMA operand roles: row / column index, k half
+    const int R = a.cam.R;
+    const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
+    const int tx0 = (tile_id % a.tiles_x) * TW, ty0 = (tile_id / a.tiles_x) * TH;
+    for (int i = tid; i < PT_ROWS * PT_STRIDE; i += H2T) {
+        const int j = min(i / PT_STRIDE, 63), x = min(i % PT_STRIDE, 63);
+        PT[i] = a.mips[j * 64 + x];
+    }
+    const int sx = tx0 + 64 * (wv & 1), sy = ty0 + 32 * (wv >> 1);
+    const float sx0 = (float)sx, sx1 = (float)(sx + 64), sy0 = (float)sy, sy1 = (float)(sy + 32);
+    const float pyc = (sy + li < R) ? (float)(sy + li) + 0.5f : __builtin_inff();
+    const int last_row = min(31, R - 1 - sy);              // last pixel row of the strip inside the image (wave-uniform)
+    float pxc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) pxc[b] = (sx + 32 * b + li < R) ? (float)(sx + 32 * b + li) + 0.5f : __builtin_inff();
+    constexpr int FOLD_EVERY = 512;                        // as kernel H2: float32 accumulators hold <= 512 footprints
+    f32x16 acc[NACC][2];
+#pragma unroll
+    for (int c = 0; c < NACC; ++c)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[c][b][v] = 0.0f;
+    unsigned long long n_frag = 0;
+    int since_fold = 0;
+    const char *PTb = reinterpret_cast<const char *>(PT);
+    __syncthreads();                                       // the only workgroup barrier
+
+    auto flush = [&]() {
+        double *img = a.img + ((size_t)(sy + 4 * kh) * R + (sx + li)) * C;
+        asm volatile("" : "+v"(img));
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = (v >> 2) * 8 + (v & 3);    // + 4 * kh (in img)
+                if (sx + 32 * b + li < R && sy + 4 * kh + row < R) {
+                    double *d = img + ((size_t)row * R + 32 * b) * C;
+#pragma unroll
+                    for (int c = 0; c < NACC; ++c) {
+                        if (acc[c][b][v] != 0.0f) gatomic_add(d + c, acc[c][b][v]);
+                        acc[c][b][v] = 0.0f;
+                    }
+                }
+            }
+    };
+
+    const long long n_runs = (a.n_records + HDEAL - 1) / HDEAL;
+    auto fetch = [&](long long run0, float4 &g, float &gw1, float &gw2) {
+        const long long ri = ((run0 + lane / HDEAL) * a.split + sp) * HDEAL + (lane & (HDEAL - 1));
+        g = make_float4(0.f, 0.f, 0.f, 0.f); gw1 = gw2 = 0.0f;
+        if (ri < a.n_records) {
+            g = a.geom[ri];
+            gw1 = a.w[ri * NW];
+            if (NW == 2) gw2 = a.w[ri * NW + 1];
+        }
+    };
+    float4 g_next; float gw1_next, gw2_next;
+    fetch(0, g_next, gw1_next, gw2_next);
+    for (long long run0 = 0; run0 * a.split < n_runs; run0 += 64 / HDEAL) {
+        const float4 g = g_next;
+        const float gw1 = gw1_next, gw2 = gw2_next;
+        fetch(run0 + 64 / HDEAL, g_next, gw1_next, gw2_next);
+        const float g_half = 0.5f * g.z;
+        bool hit;
+        {
+            const float sdx = fmaxf(fmaxf(sx0 - g.x, g.x - sx1), 0.0f), sdy = fmaxf(fmaxf(sy0 - g.y, g.y - sy1), 0.0f);
+            hit = g.z >= a.p_lo && sdx < g_half && sdy < g_half && !(a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * g.z * g.z);
+        }
+        unsigned long long hits = __ballot(hit);
+        if (hits == 0ull) continue;
+        const float g_invP = 1.0f / g.z;
+        const float g_w1 = (MODE == TSP_MODE_RGB) ? gw1 : g.w * gw1;
+        while (hits) {
+            const int src = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const float pcx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.x), src));
+            const float pcy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.y), src));
+            const float half = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_half), src));
+            const float invP = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_invP), src));
+            const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.w), src));
+            const float w1 = (NACC >= 2) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_w1), src)) : 0.0f;
+            const float w2 = (NACC >= 3) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gw2), src)) : 0.0f;
+            // ---- rows (A operand): lane (li, kh) evaluates pixel row li; canonical texel coordinate (tsp_math.h) ----
+            float fy, gy;
+            int rel, r0, nsteps;
+            {
+                const float d = pyc - pcy;
+                const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                const float v = (d + half) * invP;
+                const float tv = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, 64.0f, -0.5f), 0.0f, 63.0f);
+                const float f0 = __builtin_floorf(tv);
+                fy = (tv - f0) * cv;
+                gy = cv - fy;
+                const int r = (int)f0;
+                r0 = __builtin_amdgcn_readlane(r, 0);                 // texel row of the strip's first pixel row
+                rel = r - r0;
+                const int kmax = __builtin_amdgcn_readlane(rel, last_row);   // texel rows are monotone down the strip
+                nsteps = (kmax + 3) >> 1;                             // texel rows r0 .. r0 + kmax + 1, two per MFMA
+                if (a.count_frag) {
+                    const unsigned long long rows = __ballot(cv != 0.0f && kh == 0);
+                    const int ncx = ((__builtin_fabsf(pxc[0] - pcx) < half) ? 1 : 0) + ((__builtin_fabsf(pxc[1] - pcx) < half) ? 1 : 0);
+                    if (kh == 0) n_frag += (unsigned long long)(ncx * __popcll(rows));
+                }
+            }
+            // ---- columns (B operand): lane (li, kh) evaluates pixel columns li and 32 + li ----
+            int caddr[2];
+            float fxs[2], gxs[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float d = pxc[b] - pcx;
+                const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                const float u = (d + half) * invP;
+                const float tu = __builtin_amdgcn_fmed3f(__builtin_fmaf(u, 64.0f, -0.5f), 0.0f, 63.0f);
+                const float f0 = __builtin_floorf(tu);
+                const float fr = (tu - f0) * cv;
+                caddr[b] = ((int)f0) * 4;
+                fxs[b] = (NACC == 1) ? fr * w0 : fr;    // density: the particle weight rides on the column factors
+                gxs[b] = (NACC == 1) ? (cv - fr) * w0 : (cv - fr);
+            }
+            int rowoff = (r0 + kh) * (PT_STRIDE * 4);   // this lane's texel row of the current k-step (bytes)
+            int kk = kh;
+            for (int m = 0; m < nsteps; ++m) {
+                const float A = (rel == kk) ? gy : ((rel + 1 == kk) ? fy : 0.0f);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const float *t = reinterpret_cast<const float *>(PTb + rowoff + caddr[b]);
+                    const float L = __builtin_fmaf(t[1], fxs[b], t[0] * gxs[b]);
+                    acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, (NACC == 1) ? L : L * w0, acc[0][b], 0, 0, 0);
+                    if (NACC >= 2) acc[NACC >= 2 ? 1 : 0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, L * w1, acc[NACC >= 2 ? 1 : 0][b], 0, 0, 0);
+                    if (NACC >= 3) acc[NACC - 1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, L * w2, acc[NACC - 1][b], 0, 0, 0);
+                }
+                kk += 2;
+                rowoff += 2 * PT_STRIDE * 4;
+            }
+            if (++since_fold == FOLD_EVERY) { since_fold = 0; flush(); }
+        }
+    }
+    flush();
+    if (a.count_frag) {
+        for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
+        if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+    }
+}
+
+template <int MODE, int NACC>
+static int launch_mega(tsp_context *ctx, TileArgs ta, long long n_huge) {
+    const size_t smem = (size_t)((PT_ROWS * PT_STRIDE + 3) & ~3) * sizeof(float);
+    const int htiles_x = (ctx->R + 127) / 128, htiles_y = (ctx->R + 63) / 64;
+    const int htiles = htiles_x * htiles_y;
+    const long long batches = (n_huge + 63) / 64;
+    int split = ctx->huge_split;
+    if (split <= 0) split = std::max(1, (ctx->cu_count * 32 + htiles - 1) / htiles);
+    split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
+    ta.split = split;
+    ta.tiles_x = htiles_x;
+    hipLaunchKernelGGL((splat_mega_kernel<MODE, NACC>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
     TSP_HIP(hipGetLastError());
     return TSP_OK;
 }
@@ -1152,7 +1356,8 @@ __global__ __launch_bounds__(256) void count_apply_kernel(const int *__restrict_
     }
 }
 
-static int add_rect_counts(tsp_context *ctx, const float4 *mid_geom, long long n_mid, const float4 *huge_geom, long long n_huge) {
+static int add_rect_counts(tsp_context *ctx, const float4 *mid_geom, long long n_mid, const float4 *huge_geom, long long n_huge,
+                           const float4 *mega_geom, long long n_mega) {
     Workspace &ws = ctx->ws;
     const int R = ctx->R, S = R + 1, nb = (R + CBAND - 1) / CBAND;
     if (!ws.count_diff) {
@@ -1163,6 +1368,7 @@ static int add_rect_counts(tsp_context *ctx, const float4 *mid_geom, long long n
     TSP_HIP(hipMemsetAsync(ws.count_diff, 0, (size_t)S * S * sizeof(int), st));
     if (n_mid > 0) hipLaunchKernelGGL(rect_count_corners_kernel, dim3((unsigned)((n_mid + 255) / 256)), dim3(256), 0, st, mid_geom, n_mid, R, ws.count_diff);
     if (n_huge > 0) hipLaunchKernelGGL(rect_count_corners_kernel, dim3((unsigned)((n_huge + 255) / 256)), dim3(256), 0, st, huge_geom, n_huge, R, ws.count_diff);
+    if (n_mega > 0) hipLaunchKernelGGL(rect_count_corners_kernel, dim3((unsigned)((n_mega + 255) / 256)), dim3(256), 0, st, mega_geom, n_mega, R, ws.count_diff);
     hipLaunchKernelGGL(count_row_scan_kernel, dim3(R), dim3(256), 0, st, ws.count_diff, R);
     hipLaunchKernelGGL(count_band_sum_kernel, dim3((R + 255) / 256, nb), dim3(256), 0, st, ws.count_diff, R, ws.count_band);
     hipLaunchKernelGGL(count_apply_kernel, dim3((R + 255) / 256, nb), dim3(256), 0, st, ws.count_diff, ws.count_band, R, ctx->image64);
@@ -1265,7 +1471,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         sa.mid_geom = (float4 *)ws.mid_geom; sa.mid_w = (float *)ws.mid_w; sa.mid_capacity = ws.mid_capacity;
         sa.huge_geom = (float4 *)ws.huge_geom; sa.huge_w = (float *)ws.huge_w; sa.huge_capacity = ws.huge_capacity;
         sa.seg_count = ws.seg_count; sa.seg_offset = ws.seg_offset; sa.seg_bbox = ws.seg_bbox;
-        sa.cnt = ctx->counters; sa.p_small = ctx->p_small; sa.count_frag = ctx->count_fragments ? 1 : 0;
+        sa.cnt = ctx->counters; sa.p_small = ctx->p_small; sa.p_mega = (ctx->huge_variant != 0 && ctx->p_mega > 0.0f) ? ctx->p_mega : __builtin_inff(); sa.count_frag = ctx->count_fragments ? 1 : 0;
         sa.emit_small = attempt == 0 ? 1 : 0;
         TSP_HIP(hipEventRecord(ctx->ev[2], st));
         if (WCr == 1) hipLaunchKernelGGL((splat_stream_kernel<MODE, 1>), dim3(grid_s), dim3(256), smem_s, st, sa);
@@ -1275,7 +1481,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         // the record counts size the two tile launches (and reveal a list overflow)
         TSP_HIP(hipMemcpyAsync(&hc, ctx->counters, sizeof(hc), hipMemcpyDeviceToHost, st));
         TSP_HIP(hipStreamSynchronize(st));
-        const bool mid_over = (int64_t)hc.n_mid > ws.mid_capacity, huge_over = (int64_t)hc.n_huge > ws.huge_capacity;
+        const bool mid_over = (int64_t)hc.n_mid > ws.mid_capacity, huge_over = (int64_t)(hc.n_huge + hc.n_mega) > ws.huge_capacity;
         if (!mid_over && !huge_over) break;
         TSP_REQUIRE(attempt == 0, TSP_ENOMEM, "record lists overflowed twice");
         // enlarge and replay kernel S in records-only mode (its small footprints are already in the image)
@@ -1285,7 +1491,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
             TSP_HIP(hipMalloc(&ws.mid_w, (size_t)ws.mid_capacity * 2 * sizeof(float)));
         }
         if (huge_over) {
-            if ((rc = grow(&ws.huge_geom, &ws.huge_capacity, (int64_t)hc.n_huge + (int64_t)hc.n_huge / 8 + 1024, sizeof(float4)))) return rc;
+            if ((rc = grow(&ws.huge_geom, &ws.huge_capacity, (int64_t)(hc.n_huge + hc.n_mega) + (int64_t)(hc.n_huge + hc.n_mega) / 8 + 1024, sizeof(float4)))) return rc;
             if (ws.huge_w) TSP_HIP(hipFree(ws.huge_w));
             TSP_HIP(hipMalloc(&ws.huge_w, (size_t)ws.huge_capacity * 2 * sizeof(float)));
         }
@@ -1323,23 +1529,33 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     }
     TSP_HIP(hipEventRecord(ctx->ev[5], st_mid));
     TSP_HIP(hipEventRecord(ctx->ev[9], st));
+    const long long n_mega = (long long)hc.n_mega;
+    const float4 *mega_geom = (const float4 *)ws.huge_geom + (ws.huge_capacity - n_mega);
+    const float *mega_w = (const float *)ws.huge_w + (ws.huge_capacity - n_mega) * ((MODE == TSP_MODE_RGB) ? 2 : 1);
+    ta.p_lo = 0.0f; ta.p_hi = __builtin_inff();
     if (hc.n_huge > 0) {
         ta.geom = (const float4 *)ws.huge_geom; ta.w = (const float *)ws.huge_w; ta.n_records = (long long)hc.n_huge;
         if (ctx->huge_variant == 0) {           // kernel H (per-pixel bilinear gather), kept for A/B measurements
             if (MODE == TSP_MODE_RGB) rc = launch_huge<MODE, 3, 4>(ctx, ta, smem_h, (long long)hc.n_huge);
             else if (second_channel) rc = launch_huge<MODE, 2, 4>(ctx, ta, smem_h, (long long)hc.n_huge);
             else rc = launch_huge<MODE, 1, 4>(ctx, ta, smem_h, (long long)hc.n_huge);   // 4x8 px/lane measured slower (spills, larger tiles)
-        } else {                                // kernel H2 (row-uniform gather)
-            if (MODE == TSP_MODE_RGB) rc = launch_huge2<MODE, 3, 1, 16>(ctx, ta, (long long)hc.n_huge);
-            else if (second_channel) rc = launch_huge2<MODE, 2, 1, 16>(ctx, ta, (long long)hc.n_huge);
-            else if (ctx->huge_variant == 2) rc = launch_huge2<MODE, 1, 2, 32>(ctx, ta, (long long)hc.n_huge);
-            else rc = launch_huge2<MODE, 1, 1, 32>(ctx, ta, (long long)hc.n_huge);
+        } else {                                // kernel H2 (row-uniform gather): 64 px <= P < p_mega
+            if (MODE == TSP_MODE_RGB) rc = launch_huge2<MODE, 3, 1, 16, 4>(ctx, ta, (long long)hc.n_huge);
+            else if (second_channel) rc = launch_huge2<MODE, 2, 1, 16, 4>(ctx, ta, (long long)hc.n_huge);
+            else rc = launch_huge2<MODE, 1, 1, 32, 4>(ctx, ta, (long long)hc.n_huge);
         }
         if (rc) return rc;
     }
-    if (MODE == TSP_MODE_RGB && (hc.n_mid > 0 || hc.n_huge > 0)) {
+    if (n_mega > 0) {                           // kernel H3 (matrix cores): P >= p_mega, the tail end of the huge list
+        ta.geom = mega_geom; ta.w = mega_w; ta.n_records = n_mega;
+        if (MODE == TSP_MODE_RGB) rc = launch_mega<MODE, 3>(ctx, ta, n_mega);
+        else if (second_channel) rc = launch_mega<MODE, 2>(ctx, ta, n_mega);
+        else rc = launch_mega<MODE, 1>(ctx, ta, n_mega);
+        if (rc) return rc;
+    }
+    if (MODE == TSP_MODE_RGB && (hc.n_mid > 0 || hc.n_huge > 0 || n_mega > 0)) {
         if (ctx->overlap_mid_huge) TSP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));
-        if ((rc = add_rect_counts(ctx, (const float4 *)ws.mid_geom, (long long)hc.n_mid, (const float4 *)ws.huge_geom, (long long)hc.n_huge))) return rc;
+        if ((rc = add_rect_counts(ctx, (const float4 *)ws.mid_geom, (long long)hc.n_mid, (const float4 *)ws.huge_geom, (long long)hc.n_huge, mega_geom, n_mega))) return rc;
     }
     TSP_HIP(hipEventRecord(ctx->ev[6], st));
     if (ctx->overlap_mid_huge) TSP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));     // join: later work on `st` sees both
