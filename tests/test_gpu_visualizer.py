@@ -304,12 +304,18 @@ def test_periodic_sph_output(kats):               # reference test_periodic_sph_
     # rotated, non-integer shifts with fading weights: HIP post-pass == oracle bit for bit
     v.rotate(0.3, 0.2)
     v.scale = 130.0
-    v.render_sph(DrawReason.EXPORT)
-    tiled = v._sph._context.read_image()
-    off, w = oracle_np.periodic_instances(v.rotation_matrix, 100.0 / 130.0)
-    v._sph._context.render(*v._sph._get_transform_params(), clear=True)      # the untiled image again
+    from topsy_amd import periodic_sph, sph
+    sph.SPH.render(v._sph, DrawReason.EXPORT)     # the splat alone (two renders differ in the last bit: atomics)
     raw = v._sph._context.read_image()
+    off, w = oracle_np.periodic_instances(v.rotation_matrix, 100.0 / 130.0)
+    poff, pw = periodic_sph.instance_offsets_and_weights(v.rotation_matrix, 100.0 / 130.0)
+    assert np.array_equal(off, poff) and np.array_equal(w, pw)
+    v._sph._context.tile_periodic(poff, pw)       # what PeriodicSPH.render does next
+    tiled = v._sph._context.read_image()
     assert np.array_equal(tiled, oracle_np.periodic_tile(raw, off, w))
+    # and the product's own frame (render + tiling) agrees with it up to the summation order of the splat
+    v.render_sph(DrawReason.EXPORT)
+    npt.assert_allclose(v._sph._context.read_image(), tiled, rtol=1e-5, atol=1e-30)
     v.close()
 
 

@@ -594,6 +594,11 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         ctx->p_small = (float)value * 1e-3f;
         return TSP_OK;
     }
+    if (!strcmp(name, "mega_split")) {
+        TSP_REQUIRE(value >= 0 && value <= 4096, TSP_EINVAL, "%s out of range", name);
+        ctx->mega_split = (int)value;
+        return TSP_OK;
+    }
     if (!strcmp(name, "mid_split") || !strcmp(name, "huge_split") || !strcmp(name, "stream_blocks_per_cu")) {
         TSP_REQUIRE(value >= 0 && value <= 4096, TSP_EINVAL, "%s out of range", name);
         if (name[0] == 'm') ctx->mid_split = value > 0 ? (int)value : 1;

@@ -104,8 +104,8 @@ struct tsp_context {
     // pipeline tuning (tsp_set_option)
     float p_small = 11.3f;             // footprints narrower than this many pixels are splatted by kernel S
     float p_mega = 512.0f;            // footprints at least this wide go to kernel H3 (matrix cores); 0 = all to H2
-    int huge_variant = 1;             // 0: kernel H (per-pixel gather), 1: kernel H2 64x32 strips, 2: H2 128x16 strips (density)
-    int mid_split = 128, huge_split = 0;  // workgroups per image tile (0 = auto)
+    int huge_variant = 1;             // 0: kernel H (per-pixel gather, A/B only), 1: kernels H2 (64x16 strips) + H3, 2: H2 with 64x32 strips (density)
+    int mid_split = 128, huge_split = 0, mega_split = 0;  // workgroups per image tile (0 = auto)
     int stream_blocks_per_cu = 100;  // kernel S grid bound: ~10 chunks per workgroup at 1e8 particles balances dense and sparse chunks
     bool overlap_mid_huge = false;    // option: kernels M and H on two streams (measured: no gain at 1.25e8, +6 % at 1e7)
     int cu_count = 256;

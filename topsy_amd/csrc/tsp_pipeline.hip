@@ -943,6 +943,13 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             wq.y = (NACC >= 2) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_w1), src)) : 0.0f;
             wq.z = (NACC >= 3) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gw2), src)) : 0.0f;
             wq.w = 0.0f;
+            if (NACC >= 2) {
+                // the channel weights feed tied-operand FMAs on every row: park them in VGPRs once per footprint (left to
+                // itself the compiler re-copies the scalar before every use: three extra v_mov per row)
+                asm volatile("v_mov_b32 %0, %1" : "=v"(wq.x) : "s"(wq.x));
+                asm volatile("v_mov_b32 %0, %1" : "=v"(wq.y) : "s"(wq.y));
+                if (NACC >= 3) asm volatile("v_mov_b32 %0, %1" : "=v"(wq.z) : "s"(wq.z));
+            }
             // ---- rows: lane j < HR evaluates row j and the texel row of the row above it -----------------
             unsigned covmask, chgmask, jmpmask;
             int r512;                                   // byte offset of this lane's texel row in PT
@@ -1098,7 +1105,9 @@ static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
     const int htiles = htiles_x * htiles_y;
     const long long batches = (n_huge + 63) / 64;
     int split = ctx->huge_split;
-    if (split <= 0) split = std::max(1, (ctx->cu_count * 32 + htiles - 1) / htiles);
+    // many short workgroups: a wave lives ~1 ms at split 64 and the tail of the launch (tiles differ 10x in work)
+    // cost 2.5 ms of 21; measured 64 -> 128: 21.9 -> 19.5 ms, 256: 19.2 ms, 512: 22.5 ms
+    if (split <= 0) split = std::max(1, (ctx->cu_count * 128 + htiles - 1) / htiles);
     split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
     ta.split = split;
     ta.tiles_x = htiles_x;
@@ -1120,11 +1129,14 @@ static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
 // 64x32 strip and k-step) while the VALU only prepares ~80 instructions per footprint and strip.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int MODE, int NACC>
-__global__ __launch_bounds__(H2T, (NACC == 1) ? 4 : (NACC == 2 ? 3 : 2)) void splat_mega_kernel(TileArgs a) {
+// NB = 32-column blocks per wave strip (strip = 32 NB columns x 32 rows): the row factors and the A operand of a k-step
+// are shared by the NB column blocks, so wider strips spend fewer VALU instructions per pixel (the kernel is VALU-bound:
+// ~60 preparation instructions per footprint and strip against 2 NB MFMAs per k-step)
+template <int MODE, int NACC, int NB>
+__global__ __launch_bounds__(H2T, (NACC * NB <= 2) ? 4 : (NACC * NB <= 4 ? 3 : 2)) void splat_mega_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
-    constexpr int TW = 128, TH = 64;                       // tile: 2 x 2 wave strips of 64 x 32 pixels
+    constexpr int SW = 32 * NB, TW = 2 * SW, TH = 64;       // tile: 2 x 2 wave strips of SW x 32 pixels
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *PT = smem;                                      // [PT_ROWS][PT_STRIDE] level-0 kernel image, clamp-to-edge padded
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1136,19 +1148,19 @@ __global__ __launch_bounds__(H2T, (NACC == 1) ? 4 : (NACC == 2 ? 3 : 2)) void sp
         const int j = min(i / PT_STRIDE, 63), x = min(i % PT_STRIDE, 63);
         PT[i] = a.mips[j * 64 + x];
     }
-    const int sx = tx0 + 64 * (wv & 1), sy = ty0 + 32 * (wv >> 1);
-    const float sx0 = (float)sx, sx1 = (float)(sx + 64), sy0 = (float)sy, sy1 = (float)(sy + 32);
+    const int sx = tx0 + SW * (wv & 1), sy = ty0 + 32 * (wv >> 1);
+    const float sx0 = (float)sx, sx1 = (float)(sx + SW), sy0 = (float)sy, sy1 = (float)(sy + 32);
     const float pyc = (sy + li < R) ? (float)(sy + li) + 0.5f : __builtin_inff();
     const int last_row = min(31, R - 1 - sy);              // last pixel row of the strip inside the image (wave-uniform)
-    float pxc[2];
+    float pxc[NB];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) pxc[b] = (sx + 32 * b + li < R) ? (float)(sx + 32 * b + li) + 0.5f : __builtin_inff();
+    for (int b = 0; b < NB; ++b) pxc[b] = (sx + 32 * b + li < R) ? (float)(sx + 32 * b + li) + 0.5f : __builtin_inff();
     constexpr int FOLD_EVERY = 512;                        // as kernel H2: float32 accumulators hold <= 512 footprints
-    f32x16 acc[NACC][2];
+    f32x16 acc[NACC][NB];
 #pragma unroll
     for (int c = 0; c < NACC; ++c)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[c][b][v] = 0.0f;
     unsigned long long n_frag = 0;
@@ -1160,7 +1172,7 @@ __global__ __launch_bounds__(H2T, (NACC == 1) ? 4 : (NACC == 2 ? 3 : 2)) void sp
         double *img = a.img + ((size_t)(sy + 4 * kh) * R + (sx + li)) * C;
         asm volatile("" : "+v"(img));
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int row = (v >> 2) * 8 + (v & 3);    // + 4 * kh (in img)
@@ -1229,15 +1241,17 @@ __global__ __launch_bounds__(H2T, (NACC == 1) ? 4 : (NACC == 2 ? 3 : 2)) void sp
                 nsteps = (kmax + 3) >> 1;                             // texel rows r0 .. r0 + kmax + 1, two per MFMA
                 if (a.count_frag) {
                     const unsigned long long rows = __ballot(cv != 0.0f && kh == 0);
-                    const int ncx = ((__builtin_fabsf(pxc[0] - pcx) < half) ? 1 : 0) + ((__builtin_fabsf(pxc[1] - pcx) < half) ? 1 : 0);
+                    int ncx = 0;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) ncx += (__builtin_fabsf(pxc[b] - pcx) < half) ? 1 : 0;
                     if (kh == 0) n_frag += (unsigned long long)(ncx * __popcll(rows));
                 }
             }
-            // ---- columns (B operand): lane (li, kh) evaluates pixel columns li and 32 + li ----
-            int caddr[2];
-            float fxs[2], gxs[2];
+            // ---- columns (B operand): lane (li, kh) evaluates pixel columns 32 b + li ----
+            int caddr[NB];
+            float fxs[NB], gxs[NB];
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
+            for (int b = 0; b < NB; ++b) {
                 const float d = pxc[b] - pcx;
                 const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
                 const float u = (d + half) * invP;
@@ -1253,7 +1267,7 @@ __global__ __launch_bounds__(H2T, (NACC == 1) ? 4 : (NACC == 2 ? 3 : 2)) void sp
             for (int m = 0; m < nsteps; ++m) {
                 const float A = (rel == kk) ? gy : ((rel + 1 == kk) ? fy : 0.0f);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     const float *t = reinterpret_cast<const float *>(PTb + rowoff + caddr[b]);
                     const float L = __builtin_fmaf(t[1], fxs[b], t[0] * gxs[b]);
                     acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, (NACC == 1) ? L : L * w0, acc[0][b], 0, 0, 0);
@@ -1273,18 +1287,18 @@ __global__ __launch_bounds__(H2T, (NACC == 1) ? 4 : (NACC == 2 ? 3 : 2)) void sp
     }
 }
 
-template <int MODE, int NACC>
+template <int MODE, int NACC, int NB>
 static int launch_mega(tsp_context *ctx, TileArgs ta, long long n_huge) {
     const size_t smem = (size_t)((PT_ROWS * PT_STRIDE + 3) & ~3) * sizeof(float);
-    const int htiles_x = (ctx->R + 127) / 128, htiles_y = (ctx->R + 63) / 64;
+    const int htiles_x = (ctx->R + 64 * NB - 1) / (64 * NB), htiles_y = (ctx->R + 63) / 64;
     const int htiles = htiles_x * htiles_y;
     const long long batches = (n_huge + 63) / 64;
-    int split = ctx->huge_split;
-    if (split <= 0) split = std::max(1, (ctx->cu_count * 32 + htiles - 1) / htiles);
+    int split = ctx->mega_split;
+    if (split <= 0) split = std::max(1, (ctx->cu_count * 64 + htiles - 1) / htiles);
     split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
     ta.split = split;
     ta.tiles_x = htiles_x;
-    hipLaunchKernelGGL((splat_mega_kernel<MODE, NACC>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
+    hipLaunchKernelGGL((splat_mega_kernel<MODE, NACC, NB>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
     TSP_HIP(hipGetLastError());
     return TSP_OK;
 }
@@ -1471,7 +1485,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         sa.mid_geom = (float4 *)ws.mid_geom; sa.mid_w = (float *)ws.mid_w; sa.mid_capacity = ws.mid_capacity;
         sa.huge_geom = (float4 *)ws.huge_geom; sa.huge_w = (float *)ws.huge_w; sa.huge_capacity = ws.huge_capacity;
         sa.seg_count = ws.seg_count; sa.seg_offset = ws.seg_offset; sa.seg_bbox = ws.seg_bbox;
-        sa.cnt = ctx->counters; sa.p_small = ctx->p_small; sa.p_mega = (ctx->huge_variant != 0 && ctx->p_mega > 0.0f) ? ctx->p_mega : __builtin_inff(); sa.count_frag = ctx->count_fragments ? 1 : 0;
+        sa.cnt = ctx->counters; sa.p_small = ctx->p_small; sa.p_mega = (ctx->huge_variant != 0 && MODE != TSP_MODE_RGB && ctx->p_mega > 0.0f) ? ctx->p_mega : __builtin_inff(); sa.count_frag = ctx->count_fragments ? 1 : 0;
         sa.emit_small = attempt == 0 ? 1 : 0;
         TSP_HIP(hipEventRecord(ctx->ev[2], st));
         if (WCr == 1) hipLaunchKernelGGL((splat_stream_kernel<MODE, 1>), dim3(grid_s), dim3(256), smem_s, st, sa);
@@ -1535,22 +1549,26 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     ta.p_lo = 0.0f; ta.p_hi = __builtin_inff();
     if (hc.n_huge > 0) {
         ta.geom = (const float4 *)ws.huge_geom; ta.w = (const float *)ws.huge_w; ta.n_records = (long long)hc.n_huge;
-        if (ctx->huge_variant == 0) {           // kernel H (per-pixel bilinear gather), kept for A/B measurements
+        // rgb stays on kernel H: with three accumulators per pixel its per-pixel stencil set-up is shared by three FMAs
+        // (0.49 clk per fragment at 2048^2), while H2 pays its per-strip set-up over 16-row strips (0.62) and H3 needs
+        // three MFMAs per block and k-step (matrix-pipe-bound, 0.47)
+        if (ctx->huge_variant == 0 || MODE == TSP_MODE_RGB) {
             if (MODE == TSP_MODE_RGB) rc = launch_huge<MODE, 3, 4>(ctx, ta, smem_h, (long long)hc.n_huge);
             else if (second_channel) rc = launch_huge<MODE, 2, 4>(ctx, ta, smem_h, (long long)hc.n_huge);
             else rc = launch_huge<MODE, 1, 4>(ctx, ta, smem_h, (long long)hc.n_huge);   // 4x8 px/lane measured slower (spills, larger tiles)
         } else {                                // kernel H2 (row-uniform gather): 64 px <= P < p_mega
             if (MODE == TSP_MODE_RGB) rc = launch_huge2<MODE, 3, 1, 16, 4>(ctx, ta, (long long)hc.n_huge);
             else if (second_channel) rc = launch_huge2<MODE, 2, 1, 16, 4>(ctx, ta, (long long)hc.n_huge);
-            else rc = launch_huge2<MODE, 1, 1, 32, 4>(ctx, ta, (long long)hc.n_huge);
+            else if (ctx->huge_variant == 2) rc = launch_huge2<MODE, 1, 1, 32, 4>(ctx, ta, (long long)hc.n_huge);
+            else rc = launch_huge2<MODE, 1, 1, 16, 6>(ctx, ta, (long long)hc.n_huge);   // 64x16 strips at 6 waves/SIMD: 17.3 ms against 18.6 for 64x32 at 4
         }
         if (rc) return rc;
     }
     if (n_mega > 0) {                           // kernel H3 (matrix cores): P >= p_mega, the tail end of the huge list
         ta.geom = mega_geom; ta.w = mega_w; ta.n_records = n_mega;
-        if (MODE == TSP_MODE_RGB) rc = launch_mega<MODE, 3>(ctx, ta, n_mega);
-        else if (second_channel) rc = launch_mega<MODE, 2>(ctx, ta, n_mega);
-        else rc = launch_mega<MODE, 1>(ctx, ta, n_mega);
+        if (MODE == TSP_MODE_RGB) rc = launch_mega<MODE, 3, 2>(ctx, ta, n_mega);
+        else if (second_channel) rc = launch_mega<MODE, 2, 2>(ctx, ta, n_mega);
+        else rc = launch_mega<MODE, 1, 2>(ctx, ta, n_mega);      // 4 column blocks per strip measured no faster (18.8 vs 18.6 ms)
         if (rc) return rc;
     }
     if (MODE == TSP_MODE_RGB && (hc.n_mid > 0 || hc.n_huge > 0 || n_mega > 0)) {
