@@ -99,7 +99,7 @@ def main():
     lut = matplotlib.colormaps["twilight_shifted"](np.linspace(0.001, 0.999, 1000)).astype(np.float32)
     flags = _native.PIPE_GENERIC if args.generic else _native.PIPE_DEFAULT
 
-    kernel_ms = {"stream": [], "mid": [], "huge": [], "total": [], "reduce": []}
+    kernel_ms = {"stream": [], "mid": [], "huge": [], "mega": [], "total": [], "reduce": []}
     vmin, vmax = -12.0, -4.0
 
     def frame(record):
@@ -107,7 +107,8 @@ def main():
         if record:
             st = ctx.stats()
             kernel_ms["stream"].append(st["ms_stream"]); kernel_ms["mid"].append(st["ms_mid"])
-            kernel_ms["huge"].append(st["ms_huge"]); kernel_ms["total"].append(st["ms_total"])
+            kernel_ms["huge"].append(st["ms_huge"]); kernel_ms["mega"].append(st["ms_mega"])
+            kernel_ms["total"].append(st["ms_total"])
         if world > 1:
             ms = ctx.comm_reduce_image(root=0)
             if record:
@@ -156,13 +157,14 @@ def main():
     value = n_total / (elapsed / args.steps)
     # dominant kernel of the frame and its roofline (HBM: B_alg bytes/particle streamed once)
     means = {k: float(np.mean(v)) if v else 0.0 for k, v in kernel_ms.items()}
-    parts = {k: means[k] for k in ("stream", "mid", "huge")}
+    parts = {k: means[k] for k in ("stream", "mid", "huge", "mega")}
     if sum(parts.values()) <= 0.0:
         dom, dom_ms = "splat_generic_kernel", means["total"]
     else:
         dom = max(parts, key=parts.get)
         dom_ms = parts[dom]
-        dom = {"stream": "splat_stream_kernel", "mid": "splat_mid_kernel", "huge": "splat_huge_kernel"}[dom]
+        dom = {"stream": "splat_stream_kernel", "mid": "splat_mid_kernel", "mega": "splat_mega_kernel",
+               "huge": "splat_huge_kernel" if args.mode == "rgb" else "splat_huge2_kernel"}[dom]
     bytes_per_launch = B_ALG[args.mode] * n_per
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     stream_ms = means["stream"] if means["stream"] > 0 else means["total"]
@@ -189,7 +191,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload_name,
                    "particles_per_gpu": n_per, "resolution": R, "sharding": f"index-range x{world}",
-                   "pipeline": "generic" if args.generic else "three-class",
+                   "pipeline": "generic" if args.generic else "four-class (stream / mid scatter / row-uniform gather / MFMA)",
                    "fragments_per_particle": frags / n_total, "frames_per_s": 1e3 / ms_per_step},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "GB per launch (PMC)", "kernel_ms": dom_ms,

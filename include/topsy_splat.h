@@ -190,10 +190,12 @@ typedef struct {
     int64_t n_particles;   /* particles visited (sum of range lengths) */
     int64_t n_small;       /* splatted by the streaming kernel */
     int64_t n_mid;         /* nearest-mip footprints deferred to the tile-scatter kernel */
-    int64_t n_huge;        /* bilinear footprints (P >= 64 px) deferred to the tile-gather kernel */
+    int64_t n_huge;        /* bilinear footprints (P >= 64 px) deferred to the tile-gather kernels (incl. n_mega) */
     int64_t n_culled;      /* z-slab / off-screen / non-finite */
     int64_t n_fragments;   /* pixel updates (only counted when TSP_STATS is enabled) */
-    double ms_stream, ms_mid, ms_huge, ms_total; /* per-kernel GPU time, hipEvents */
+    double ms_stream, ms_mid, ms_huge, ms_total; /* per-kernel GPU time, hipEvents; ms_huge = kernel H or H2 */
+    double ms_mega;        /* kernel H3 (footprints >= p_mega px on the matrix cores); 0 when it did not run */
+    int64_t n_mega;        /* footprints handled by kernel H3 */
 } tsp_stats;
 int tsp_get_stats(tsp_context *ctx, tsp_stats *out);
 /* Enable fragment counting (adds atomics; off by default). */

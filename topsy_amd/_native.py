@@ -30,7 +30,7 @@ class Stats(ctypes.Structure):
     _fields_ = [("n_particles", ctypes.c_int64), ("n_small", ctypes.c_int64), ("n_mid", ctypes.c_int64),
                 ("n_huge", ctypes.c_int64), ("n_culled", ctypes.c_int64), ("n_fragments", ctypes.c_int64),
                 ("ms_stream", ctypes.c_double), ("ms_mid", ctypes.c_double), ("ms_huge", ctypes.c_double),
-                ("ms_total", ctypes.c_double)]
+                ("ms_total", ctypes.c_double), ("ms_mega", ctypes.c_double), ("n_mega", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

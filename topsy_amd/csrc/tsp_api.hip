@@ -382,6 +382,7 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
     ctx->stats.n_small = (int64_t)hc.n_small;
     ctx->stats.n_mid = (int64_t)hc.n_mid;
     ctx->stats.n_huge = (int64_t)(hc.n_huge + hc.n_mega);
+    ctx->stats.n_mega = (int64_t)hc.n_mega;
     ctx->stats.n_culled = (int64_t)hc.n_culled;
     ctx->stats.n_fragments = (int64_t)hc.n_fragments;
     if (gpu_ms_out) *gpu_ms_out = ms;

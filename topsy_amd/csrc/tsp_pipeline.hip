@@ -1564,6 +1564,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         }
         if (rc) return rc;
     }
+    TSP_HIP(hipEventRecord(ctx->ev[10], st));
     if (n_mega > 0) {                           // kernel H3 (matrix cores): P >= p_mega, the tail end of the huge list
         ta.geom = mega_geom; ta.w = mega_w; ta.n_records = n_mega;
         if (MODE == TSP_MODE_RGB) rc = launch_mega<MODE, 3, 2>(ctx, ta, n_mega);
@@ -1571,6 +1572,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         else rc = launch_mega<MODE, 1, 2>(ctx, ta, n_mega);      // 4 column blocks per strip measured no faster (18.8 vs 18.6 ms)
         if (rc) return rc;
     }
+    TSP_HIP(hipEventRecord(ctx->ev[11], st));
     if (MODE == TSP_MODE_RGB && (hc.n_mid > 0 || hc.n_huge > 0 || n_mega > 0)) {
         if (ctx->overlap_mid_huge) TSP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));
         if ((rc = add_rect_counts(ctx, (const float4 *)ws.mid_geom, (long long)hc.n_mid, (const float4 *)ws.huge_geom, (long long)hc.n_huge, mega_geom, n_mega))) return rc;
@@ -1581,7 +1583,8 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     float ms = 0.f;
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_stream = ms;
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->stats.ms_mid = ms;
-    TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[6])); ctx->stats.ms_huge = ms;
+    TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10])); ctx->stats.ms_huge = ms;
+    TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[10], ctx->ev[11])); ctx->stats.ms_mega = ms;
     return TSP_OK;
 }
 
