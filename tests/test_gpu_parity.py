@@ -446,3 +446,92 @@ def test_randomised_views(native, mips, seed):
         if mode == "rgb":
             assert np.array_equal(got[..., 3], want[..., 3])
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["weighted", "depth", "rgb"])
+@pytest.mark.parametrize("R", [200, 1024])
+def test_gather_kernel_class_boundaries(native, mips, mode, R):
+    """Footprints right at the class boundaries of the tile-gather kernels -- 64 px (nearest mip 0 -> bilinear: kernel M
+    -> H2; a texel row per pixel row, the one case where rounding may skip a texel row) and p_mega = 512 px (H2 -> H3 on
+    the matrix cores) -- at arbitrary sub-pixel centres, partly off-screen, against the oracle: image within 1e-5 and
+    the exact fragment count.  R = 200 leaves partial tiles and strips on both axes."""
+    from oracle import oracle_np
+    scale = 100.0
+    M, sf = oracle_np.transform_matrix(_rot(0.0, 0.0), np.zeros(3), scale)
+    widths = np.array([63.99, 64.0, 64.0001, 64.001, 64.5, 65.0, 90.0, 127.9, 128.0, 200.3, 511.9, 511.999, 512.0, 512.001,
+                       700.0, 1023.0, 1024.0, 3000.0, 20000.0], dtype=np.float64)
+    rs = np.random.RandomState(77)
+    reps = 6
+    P = np.repeat(widths, reps)
+    n = len(P)
+    h = (P * scale / (2.0 * R)).astype(np.float32)
+    pos = np.zeros((n, 3), dtype=np.float32)
+    pos[:, 0] = rs.uniform(-1.3, 1.3, n) * scale
+    pos[:, 1] = rs.uniform(-1.3, 1.3, n) * scale
+    pos[:, 2] = rs.uniform(-0.9, 0.9, n) * scale
+    pos[::7, :2] = np.round(pos[::7, :2] / (2 * scale / R)) * (2 * scale / R)      # centres on pixel corners: ties
+    m = rs.uniform(0.5, 2.0, n).astype(np.float32)
+    q = rs.normal(size=n).astype(np.float32)
+    rgb = rs.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32)
+    ctx = native.Context(R, 4 if mode == "rgb" else 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, None if mode == "rgb" else m)
+    for count in (1, 0):                       # with fragment statistics (no disc culling), then with the exact culling
+        ctx.set_option("count_fragments", count)
+        if mode == "rgb":
+            ctx.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
+            ctx.render(M, sf, mode=native.MODE_RGB)
+            want, nfrag = oracle_render(pos, h, rgb[:, 0].copy(), rgb[:, 1].copy(), rgb[:, 2].copy(), 2, M, sf, R, mips)
+            got = ctx.read_image()
+            assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=0)
+            assert np.array_equal(got[..., 3], want[..., 3])
+        elif mode == "depth":
+            ctx.render(M, sf, mode=native.MODE_DEPTH)
+            want, nfrag = oracle_render(pos, h, m, None, None, 1, M, sf, R, mips)
+            assert np.allclose(ctx.read_image(), want, rtol=1e-5, atol=0)
+        else:
+            ctx.upload_quantity(q)
+            ctx.render(M, sf, mode=native.MODE_WEIGHTED)
+            want, nfrag = oracle_render(pos, h, m, q, None, 0, M, sf, R, mips)
+            check_2ch(ctx.read_image(), want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
+        st = ctx.stats()
+        if count:
+            assert st["n_fragments"] == nfrag
+        if mode == "rgb":                       # rgb keeps kernel H for everything >= 64 px
+            assert st["n_mega"] == 0
+        else:                                   # (some of them are off-screen or outside the z-slab)
+            assert 0 < st["n_mega"] <= int((h.astype(np.float64) * 2.0 * R / scale >= 512.0).sum())
+    ctx.close()
+
+
+def test_gather_kernels_fold_their_accumulators(native, mips):
+    """More than 512 footprints per wave strip: kernels H2 and H3 flush their float32 accumulators to the float64 target
+    every 512 footprints (forced here by one workgroup per tile); density stays within 1e-5 of the oracle, and the class
+    split (H2 alone against H2 + H3) does not change the image beyond the summation order."""
+    from oracle import oracle_np
+    R, scale, n = 160, 100.0, 2600
+    M, sf = oracle_np.transform_matrix(np.eye(3), np.zeros(3), scale)
+    rs = np.random.RandomState(5)
+    pos = np.zeros((n, 3), dtype=np.float32)
+    pos[:, :2] = rs.uniform(-0.8, 0.8, size=(n, 2)) * scale
+    P = np.where(np.arange(n) % 2 == 0, rs.uniform(70.0, 400.0, n), rs.uniform(520.0, 3000.0, n))
+    h = (P * scale / (2.0 * R)).astype(np.float32)
+    m = rs.uniform(0.5, 2.0, n).astype(np.float32)
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+    ctx.set_option("huge_split", 1)
+    ctx.set_option("mega_split", 1)
+    ctx.render(M, sf)
+    got = ctx.read_image()
+    assert ctx.stats()["n_mega"] == n // 2 and ctx.stats()["n_huge"] == n
+    want, _ = oracle_render(pos, h, m, None, None, 0, M, sf, R, mips)
+    assert np.allclose(got[..., 0], want[..., 0], rtol=1e-5, atol=0)
+    ctx.set_option("p_mega_px", 0)             # everything >= 64 px through kernel H2
+    ctx.render(M, sf)
+    assert ctx.stats()["n_mega"] == 0
+    assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0)
+    ctx.set_option("huge_variant", 0)          # and through the round-1 kernel H
+    ctx.render(M, sf)
+    assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0)
+    ctx.close()

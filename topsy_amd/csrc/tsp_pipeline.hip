@@ -1132,8 +1132,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // NB = 32-column blocks per wave strip (strip = 32 NB columns x 32 rows): the row factors and the A operand of a k-step
 // are shared by the NB column blocks, so wider strips spend fewer VALU instructions per pixel (the kernel is VALU-bound:
 // ~60 preparation instructions per footprint and strip against 2 NB MFMAs per k-step)
-template <int MODE, int NACC, int NB>
-__global__ __launch_bounds__(H2T, (NACC * NB <= 2) ? 4 : (NACC * NB <= 4 ? 3 : 2)) void splat_mega_kernel(TileArgs a) {
+template <int MODE, int NACC, int NB, int OCC>
+__global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
     constexpr int SW = 32 * NB, TW = 2 * SW, TH = 64;       // tile: 2 x 2 wave strips of SW x 32 pixels
@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(H2T, (NACC * NB <= 2) ? 4 : (NACC * NB <= 4 ? 3 : 2
     }
 }
 
-template <int MODE, int NACC, int NB>
+template <int MODE, int NACC, int NB, int OCC>
 static int launch_mega(tsp_context *ctx, TileArgs ta, long long n_huge) {
     const size_t smem = (size_t)((PT_ROWS * PT_STRIDE + 3) & ~3) * sizeof(float);
     const int htiles_x = (ctx->R + 64 * NB - 1) / (64 * NB), htiles_y = (ctx->R + 63) / 64;
@@ -1298,7 +1298,7 @@ static int launch_mega(tsp_context *ctx, TileArgs ta, long long n_huge) {
     split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
     ta.split = split;
     ta.tiles_x = htiles_x;
-    hipLaunchKernelGGL((splat_mega_kernel<MODE, NACC, NB>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
+    hipLaunchKernelGGL((splat_mega_kernel<MODE, NACC, NB, OCC>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
     TSP_HIP(hipGetLastError());
     return TSP_OK;
 }
@@ -1567,9 +1567,12 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     TSP_HIP(hipEventRecord(ctx->ev[10], st));
     if (n_mega > 0) {                           // kernel H3 (matrix cores): P >= p_mega, the tail end of the huge list
         ta.geom = mega_geom; ta.w = mega_w; ta.n_records = n_mega;
-        if (MODE == TSP_MODE_RGB) rc = launch_mega<MODE, 3, 2>(ctx, ta, n_mega);
-        else if (second_channel) rc = launch_mega<MODE, 2, 2>(ctx, ta, n_mega);
-        else rc = launch_mega<MODE, 1, 2>(ctx, ta, n_mega);      // 4 column blocks per strip measured no faster (18.8 vs 18.6 ms)
+        if (MODE == TSP_MODE_RGB) rc = launch_mega<MODE, 3, 2, 2>(ctx, ta, n_mega);
+        else if (second_channel) rc = launch_mega<MODE, 2, 2, 3>(ctx, ta, n_mega);
+        else if (ctx->huge_variant == 5) rc = launch_mega<MODE, 1, 2, 5>(ctx, ta, n_mega);
+        else if (ctx->huge_variant == 6) rc = launch_mega<MODE, 1, 2, 6>(ctx, ta, n_mega);
+        else if (ctx->huge_variant == 7) rc = launch_mega<MODE, 1, 1, 8>(ctx, ta, n_mega);
+        else rc = launch_mega<MODE, 1, 2, 4>(ctx, ta, n_mega);   // 4 column blocks per strip measured no faster (18.8 vs 18.6 ms)
         if (rc) return rc;
     }
     TSP_HIP(hipEventRecord(ctx->ev[11], st));
