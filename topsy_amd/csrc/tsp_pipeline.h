@@ -1,0 +1,52 @@
+// tsp_pipeline.h -- what the translation units of the splat pipeline share: tile constants, the float64 atomic helpers,
+// the argument block of the tile kernels, and the launcher of the tile-gather kernels (tsp_gather.hip).
+#pragma once
+#include "tsp_internal.h"
+
+namespace tsp {
+
+
+constexpr int CHUNK = 512;           // particles per chunk
+constexpr int KPT = CHUNK / 256;     // particles per thread per chunk
+constexpr int TILE = 64;             // image tile edge of kernel H (and tile width of kernel M)
+constexpr int MTILE_H = 32;          // tile height of kernel M (64 x 32 pixels per workgroup)
+constexpr int MSTR = 72;             // LDS row stride (doubles) of the mid tile
+// LDS accumulators are DOUBLE: on gfx950 a conflict-free ds_add_f64 costs ~9 clk per wave-instruction
+// (~11 clk more per extra lane on the same address) while ds_add_f32 costs ~190 (measured,
+// tools/ubench/lds_partial.hip, lds_atomics.hip), and the sums gain precision.
+template <int MODE> struct WinSize { static constexpr int value = (MODE == TSP_MODE_RGB) ? 48 : 64; };
+
+enum { CLS_NONE = 0, CLS_SMALL = 1, CLS_MID = 2, CLS_HUGE = 3, CLS_MEGA = 4 };
+
+// the render target is accumulated in float64 (global_atomic_add_f64) and rounded to float32 once per
+// tsp_render call, so cross-workgroup summation adds no float32 noise however many flushes hit a pixel
+__device__ __forceinline__ void gatomic_add(double *addr, double v) {
+    __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void latomic_add(double *addr, float v) {
+    __hip_atomic_fetch_add(addr, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+constexpr int HDEAL = 4;             // records per dealing run of the tile-gather kernels
+
+struct TileArgs {
+    const float4 *geom; const float *w;
+    long long n_records;
+    const int *seg_count; const long long *seg_offset; const float4 *seg_bbox; int n_chunks;
+    Camera cam;
+    const float *mips;
+    double *img;
+    Counters *cnt;
+    int tiles_x, split;
+    int count_frag;
+    float disc_k2;     // (0.5235)^2 when the LUT is zero outside the inscribed disc (exact corner culling), else 0
+    float p_lo, p_hi;  // kernels H2 / H3 take the records with p_lo <= P < p_hi
+};
+
+// Kernels H / H2 / H3 (tsp_gather.hip) for the footprints >= 64 px of one render block: `huge_*` = the records with
+// 64 px <= P < p_mega (all of them in rgb mode), `mega_*` = the records with P >= p_mega.  Records ctx->ev[10] between
+// the two launches and ctx->ev[11] after them (per-kernel times).
+int launch_gather_kernels(tsp_context *ctx, TileArgs ta, int mode, bool second_channel, const float4 *huge_geom,
+                          const float *huge_w, long long n_huge, const float4 *mega_geom, const float *mega_w, long long n_mega);
+
+}  // namespace tsp
