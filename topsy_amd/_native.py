@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtopsy_splat.so")
+LIB_PATH = os.environ.get("TOPSY_SPLAT_LIB") or os.path.join(_HERE, "libtopsy_splat.so")    # TOPSY_SPLAT_LIB: an alternative build (A/B measurements)
 
 MODE_WEIGHTED, MODE_DEPTH, MODE_RGB = 0, 1, 2
 PIPE_DEFAULT, PIPE_GENERIC = 0, 1

@@ -14,7 +14,16 @@ constexpr int MSTR = 72;             // LDS row stride (doubles) of the mid tile
 // LDS accumulators are DOUBLE: on gfx950 a conflict-free ds_add_f64 costs ~9 clk per wave-instruction
 // (~11 clk more per extra lane on the same address) while ds_add_f32 costs ~190 (measured,
 // tools/ubench/lds_partial.hip, lds_atomics.hip), and the sums gain precision.
-template <int MODE> struct WinSize { static constexpr int value = (MODE == TSP_MODE_RGB) ? 48 : 64; };
+#ifndef TSP_WIN1
+#define TSP_WIN1 60
+#define TSP_WIN2 44
+#define TSP_WIN4 40
+#endif
+#ifndef TSP_S_OCC
+#define TSP_S_OCC 5
+#endif
+// edge of kernel S's LDS window by the number of channels it holds (1: density, 2: weighted / depth, 4: rgb)
+template <int WC> struct WinSize { static constexpr int value = (WC == 1) ? TSP_WIN1 : (WC == 2 ? TSP_WIN2 : TSP_WIN4); };
 
 enum { CLS_NONE = 0, CLS_SMALL = 1, CLS_MID = 2, CLS_HUGE = 3, CLS_MEGA = 4 };
 

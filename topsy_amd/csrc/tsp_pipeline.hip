@@ -72,10 +72,10 @@ struct StreamArgs {
 // WC = channels kept in the LDS window: 1 for a density-only render (channel 1 is identically 0:
 // half the LDS and half the atomics), else the image's channel count.
 template <int MODE, int WC>
-__global__ __launch_bounds__(256, 5) void splat_stream_kernel(StreamArgs a) {
+__global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;      // extra weights per record
-    constexpr int WIN = WinSize<MODE>::value;
+    constexpr int WIN = WinSize<WC>::value;
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
     double *win = smem_d;                                            // [WC][WIN*WIN]
     float *T3 = reinterpret_cast<float *>(win + WC * WIN * WIN);     // mip level 3: 8x8
@@ -657,16 +657,16 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     Particles parts = ctx->p;
     if (!ctx->use_quantity) parts.q = nullptr;
     const int tiles_x = (ctx->R + TILE - 1) / TILE;
-    constexpr int WIN = WinSize<MODE>::value;
     const bool second_channel = (MODE == TSP_MODE_DEPTH) || (MODE == TSP_MODE_RGB) || (ctx->p.q != nullptr && ctx->use_quantity);
     const int WCr = (MODE == TSP_MODE_RGB) ? 4 : (second_channel ? 2 : 1);
+    const int WIN = (WCr == 1) ? WinSize<1>::value : WinSize<C>::value;
     const size_t smem_s = (size_t)WCr * WIN * WIN * sizeof(double) + 64 * sizeof(float);
     constexpr int WCM = (MODE == TSP_MODE_RGB) ? 3 : C;      // LDS tile channels of kernel M (rgb: values only)
     const size_t smem_m = (size_t)(WCr == 1 ? 1 : WCM) * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float);
     const int mtiles_y = (ctx->R + MTILE_H - 1) / MTILE_H;
     if (!(ctx->kernel_attr_done & (1u << MODE))) {
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WIN * WIN * sizeof(double) + 256)));
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WIN * WIN * sizeof(double) + 256)));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WinSize<C>::value * WinSize<C>::value * sizeof(double) + 256)));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WinSize<1>::value * WinSize<1>::value * sizeof(double) + 256)));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, WCM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
         ctx->kernel_attr_done |= 1u << MODE;
