@@ -9,7 +9,9 @@ namespace tsp {
 constexpr int CHUNK = 512;           // particles per chunk
 constexpr int KPT = CHUNK / 256;     // particles per thread per chunk
 constexpr int TILE = 64;             // image tile edge of kernel H (and tile width of kernel M)
-constexpr int MTILE_H = 32;          // tile height of kernel M (64 x 32 pixels per workgroup)
+// tile height of kernel M by the number of channels in its LDS tile: 64 x 32 pixels for a density render; 64 x 16 with
+// two or three channels, so that two (rgb) or three workgroups still fit a CU's LDS (rgb: M 31.9 -> 21.0 ms)
+constexpr int mtile_h(int wc) { return wc == 1 ? 32 : 16; }
 constexpr int MSTR = 72;             // LDS row stride (doubles) of the mid tile
 // LDS accumulators are DOUBLE: on gfx950 a conflict-free ds_add_f64 costs ~9 clk per wave-instruction
 // (~11 clk more per extra lane on the same address) while ds_add_f32 costs ~190 (measured,

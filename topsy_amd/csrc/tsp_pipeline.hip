@@ -353,6 +353,7 @@ template <int MODE, int WC>
 __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
+    constexpr int MTILE_H = mtile_h(WC);
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
     double *tile = smem_d;                                                   // [WC][MTILE_H][MSTR]
     float *T = reinterpret_cast<float *>(tile + WC * MTILE_H * MSTR);        // mip pyramid, 5440 floats
@@ -662,13 +663,14 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     const int WIN = (WCr == 1) ? WinSize<1>::value : WinSize<C>::value;
     const size_t smem_s = (size_t)WCr * WIN * WIN * sizeof(double) + 64 * sizeof(float);
     constexpr int WCM = (MODE == TSP_MODE_RGB) ? 3 : C;      // LDS tile channels of kernel M (rgb: values only)
-    const size_t smem_m = (size_t)(WCr == 1 ? 1 : WCM) * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float);
-    const int mtiles_y = (ctx->R + MTILE_H - 1) / MTILE_H;
+    const int mth = mtile_h(WCr == 1 ? 1 : WCM);
+    const size_t smem_m = (size_t)(WCr == 1 ? 1 : WCM) * mth * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float);
+    const int mtiles_y = (ctx->R + mth - 1) / mth;
     if (!(ctx->kernel_attr_done & (1u << MODE))) {
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WinSize<C>::value * WinSize<C>::value * sizeof(double) + 256)));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WinSize<1>::value * WinSize<1>::value * sizeof(double) + 256)));
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, WCM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * MTILE_H * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, WCM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * 32 * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * 32 * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
         ctx->kernel_attr_done |= 1u << MODE;
     }
 
@@ -737,7 +739,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     TSP_HIP(hipEventRecord(ctx->ev[4], st_mid));
     if (hc.n_mid > 0) {
         ta.geom = (const float4 *)ws.mid_geom; ta.w = (const float *)ws.mid_w; ta.n_records = (long long)hc.n_mid;
-        ta.split = ctx->mid_split;
+        ta.split = std::max(1, ctx->mid_split * mth / 32);     // the same number of workgroups per image area for both tile heights
         if (WCr == 1) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1>), dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st_mid, ta);
         else hipLaunchKernelGGL((splat_mid_kernel<MODE, WCM>), dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st_mid, ta);
         TSP_HIP(hipGetLastError());
