@@ -535,3 +535,23 @@ def test_gather_kernels_fold_their_accumulators(native, mips):
     ctx.render(M, sf)
     assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0)
     ctx.close()
+
+
+def test_asymmetric_kernel_lut_uses_full_tables(native, mips):
+    """Kernel M keeps only one quadrant of every mip level in LDS when the uploaded LUT is mirror-symmetric bit for bit
+    (the reference's radial kernel is); any other LUT must go through the full tables.  Both against the oracle."""
+    from oracle import oracle_np
+    M, sf = oracle_np.transform_matrix(_rot(0.2, -0.4), np.zeros(3), 120.0)
+    pos, h, m, q, _ = make_cloud(20000, seed=9)
+    rs = np.random.RandomState(2)
+    skew = mips.copy()
+    skew *= (1.0 + 0.05 * rs.uniform(size=skew.shape)).astype(np.float32)      # no symmetry left, corners no longer zero
+    for lut in (mips, skew):
+        ctx = native.Context(300, 2)
+        ctx.set_kernel_mips(lut)
+        ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+        ctx.upload_quantity(q)
+        ctx.render(M, sf)
+        want, _ = oracle_render(pos, h, m, q, None, 0, M, sf, 300, lut)
+        check_2ch(ctx.read_image(), want, abs_terms_image(pos, h, m, q, M, sf, 300, lut))
+        ctx.close()

@@ -191,6 +191,15 @@ int tsp_set_kernel_mips(tsp_context *ctx, const float *lut, int n0, int n_levels
             }
     }
     ctx->lut_zero_outside_disc = zero;
+    // mirror symmetry, bit for bit (kernel M then keeps one quadrant of every level in LDS)
+    bool sym = true;
+    for (int l = 0, off = 0; l < 4 && sym; off += (64 >> l) * (64 >> l), ++l) {
+        const int n = 64 >> l;
+        for (int j = 0; j < n && sym; ++j)
+            for (int i = 0; i < n; ++i)
+                if (memcmp(&lut[off + j * n + i], &lut[off + j * n + (n - 1 - i)], 4) || memcmp(&lut[off + j * n + i], &lut[off + (n - 1 - j) * n + i], 4)) { sym = false; break; }
+    }
+    ctx->lut_mirror_symmetric = sym;
     return TSP_OK;
 }
 
@@ -593,6 +602,11 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
     if (!strcmp(name, "p_small_milli")) {     // class boundary small/mid in 1/1000 px (<= 11313: small is always mip 3)
         TSP_REQUIRE(value >= 0 && value <= 11313, TSP_EINVAL, "p_small out of range");
         ctx->p_small = (float)value * 1e-3f;
+        return TSP_OK;
+    }
+    if (!strcmp(name, "debug_extra_lds")) {
+        TSP_REQUIRE(value >= 0 && value <= 65536, TSP_EINVAL, "%s out of range", name);
+        ctx->debug_extra_lds = (int)value;
         return TSP_OK;
     }
     if (!strcmp(name, "mega_split")) {

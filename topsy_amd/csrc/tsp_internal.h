@@ -81,6 +81,7 @@ struct tsp_context {
     double *image64 = nullptr;        // float64 master copy every kernel accumulates into (rounded once per render)
     float *mips = nullptr;            // 5440 floats
     bool have_mips = false;
+    bool lut_mirror_symmetric = false;    // every mip level equals its left-right and top-bottom mirror images bit for bit
     bool lut_zero_outside_disc = false;   // every level-0 texel whose centre is >= 2h from the centre is exactly 0
     tsp::Particles p;
     tsp::Counters *counters = nullptr;
@@ -108,6 +109,7 @@ struct tsp_context {
     int mid_split = 128, huge_split = 0, mega_split = 0;  // workgroups per image tile (0 = auto)
     int stream_blocks_per_cu = 100;  // kernel S grid bound: ~10 chunks per workgroup at 1e8 particles balances dense and sparse chunks
     bool overlap_mid_huge = false;    // option: kernels M and H on two streams (measured: no gain at 1.25e8, +6 % at 1e7)
+    int debug_extra_lds = 0;         // measurement aid: extra dynamic LDS per workgroup of kernel M (lowers its occupancy)
     int cu_count = 256;
     // RCCL
     void *comm = nullptr;

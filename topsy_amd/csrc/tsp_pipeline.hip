@@ -348,15 +348,22 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
 
 constexpr int MT = 512;              // threads per workgroup of kernel M (8 waves share tile + LUT)
 
-// WC = channels accumulated in the LDS tile (1 for a density-only render, else the image's channel count)
-template <int MODE, int WC>
+// LUT quadrants: the kernel image is a radial function sampled on a grid symmetric about its centre, so every mip level
+// equals its mirror images bit for bit (checked at upload, tsp_set_kernel_mips).  Kernel M then keeps only the top-left
+// quadrant of each level in LDS -- 5.4 KB instead of 21.8 KB -- where that raises the occupancy (rgb), and folds a texel index once per row / column block: i -> min(i, n - 1 - i).
+constexpr int MIPQ_TOTAL = 1024 + 256 + 64 + 16;
+__device__ __forceinline__ int mipq_offset(int lvl) { return lvl == 0 ? 0 : (lvl == 1 ? 1024 : (lvl == 2 ? 1280 : 1344)); }
+
+// WC = channels accumulated in the LDS tile (1 for a density-only render, else the image's channel count);
+// QUAD = the LUT is mirror-symmetric: quadrant tables
+template <int MODE, int WC, bool QUAD>
 __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
     constexpr int MTILE_H = mtile_h(WC);
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
     double *tile = smem_d;                                                   // [WC][MTILE_H][MSTR]
-    float *T = reinterpret_cast<float *>(tile + WC * MTILE_H * MSTR);        // mip pyramid, 5440 floats
+    float *T = reinterpret_cast<float *>(tile + WC * MTILE_H * MSTR);        // mip pyramid: 5440 floats, or 1360 (quadrants)
     __shared__ long long s_seg_off[MT];
     __shared__ int s_seg_cnt[MT];
     __shared__ int s_wcnt[MT / 64];
@@ -365,7 +372,15 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
     const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
     const int tx0 = (tile_id % a.tiles_x) * TILE, ty0 = (tile_id / a.tiles_x) * MTILE_H;
     const float fx0 = (float)tx0, fy0 = (float)ty0, fx1 = (float)(tx0 + TILE), fy1 = (float)(ty0 + MTILE_H);
-    for (int i = tid; i < MIP_TOTAL; i += MT) T[i] = a.mips[i];
+    if (QUAD) {
+        for (int i = tid; i < MIPQ_TOTAL; i += MT) {
+            const int lvl = i < 1024 ? 0 : (i < 1280 ? 1 : (i < 1344 ? 2 : 3));
+            const int hn = 32 >> lvl, k = i - mipq_offset(lvl);
+            T[i] = a.mips[mip_offset(lvl) + (k / hn) * (2 * hn) + (k % hn)];
+        }
+    } else {
+        for (int i = tid; i < MIP_TOTAL; i += MT) T[i] = a.mips[i];
+    }
     for (int i = tid; i < WC * MTILE_H * MSTR; i += MT) tile[i] = 0.0;
     __syncthreads();
     const int lx = lane & 7, ly = lane >> 3;
@@ -449,7 +464,7 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                     const float w2 = (NW == 2) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gw2), src)) : 0.0f;
                     const int pk = __builtin_amdgcn_readlane(packed, src);
                     const int ilo = pk & 63, ihi = (pk >> 6) & 63, jlo = (pk >> 12) & 63, jhi = (pk >> 18) & 63, lvl = pk >> 24;
-                    const int n = 64 >> lvl, toff = mip_offset(lvl);
+                    const int n = 64 >> lvl, toff = QUAD ? mipq_offset(lvl) : mip_offset(lvl), tstride = QUAD ? (n >> 1) : n;
                     // texel row of this lane's pixel row in each 8-row block of the footprint (the tile is 32 rows: <= 4 blocks)
                     int trow[MTILE_H / 8];
 #pragma unroll
@@ -458,14 +473,16 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                         if (jlo + 8 * rb <= jhi) {
                             const int j = jlo + 8 * rb + ly;
                             const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
-                            const int ty = nearest_index((dy + q_half) * q_invP, n);
-                            trow[rb] = (j <= jhi) ? toff + ty * n : -1;
+                            int ty = nearest_index((dy + q_half) * q_invP, n);
+                            if (QUAD) ty = min(ty, n - 1 - ty);
+                            trow[rb] = (j <= jhi) ? toff + ty * tstride : -1;
                         }
                     }
                     for (int ib = ilo; ib <= ihi; ib += 8) {
                         const int i = ib + lx;
                         const float dx = ((float)(tx0 + i) + 0.5f) - q_pcx;
-                        const int tx = nearest_index((dx + q_half) * q_invP, n);
+                        int tx = nearest_index((dx + q_half) * q_invP, n);
+                        if (QUAD) tx = min(tx, n - 1 - tx);
                         double *dcol = tile + (jlo + ly) * MSTR + i;
 #pragma unroll
                         for (int rb = 0; rb < MTILE_H / 8; ++rb) {
@@ -664,13 +681,19 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     const size_t smem_s = (size_t)WCr * WIN * WIN * sizeof(double) + 64 * sizeof(float);
     constexpr int WCM = (MODE == TSP_MODE_RGB) ? 3 : C;      // LDS tile channels of kernel M (rgb: values only)
     const int mth = mtile_h(WCr == 1 ? 1 : WCM);
-    const size_t smem_m = (size_t)(WCr == 1 ? 1 : WCM) * mth * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float);
+    // quadrant tables pay where LDS limits the occupancy: rgb (three channels: 2 -> 4 workgroups per CU, 21.0 -> 17.1 ms);
+    // a density render already fits three workgroups and measured slower with four (7.6 vs 7.2 ms: LDS-atomic-bound)
+    const bool quad = ctx->lut_mirror_symmetric && MODE == TSP_MODE_RGB;
+    const size_t smem_m = (size_t)(WCr == 1 ? 1 : WCM) * mth * MSTR * sizeof(double) + (quad ? MIPQ_TOTAL : MIP_TOTAL) * sizeof(float) + (size_t)ctx->debug_extra_lds;
     const int mtiles_y = (ctx->R + mth - 1) / mth;
     if (!(ctx->kernel_attr_done & (1u << MODE))) {
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WinSize<C>::value * WinSize<C>::value * sizeof(double) + 256)));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WinSize<1>::value * WinSize<1>::value * sizeof(double) + 256)));
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, WCM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * 32 * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * 32 * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float))));
+        const int lds_m = (int)((size_t)C * 32 * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, WCM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, WCM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
         ctx->kernel_attr_done |= 1u << MODE;
     }
 
@@ -740,8 +763,11 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     if (hc.n_mid > 0) {
         ta.geom = (const float4 *)ws.mid_geom; ta.w = (const float *)ws.mid_w; ta.n_records = (long long)hc.n_mid;
         ta.split = std::max(1, ctx->mid_split * mth / 32);     // the same number of workgroups per image area for both tile heights
-        if (WCr == 1) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1>), dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st_mid, ta);
-        else hipLaunchKernelGGL((splat_mid_kernel<MODE, WCM>), dim3(tiles_x * mtiles_y * ta.split), dim3(MT), smem_m, st_mid, ta);
+        const dim3 grid_m(tiles_x * mtiles_y * ta.split);
+        if (WCr == 1 && quad) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1, true>), grid_m, dim3(MT), smem_m, st_mid, ta);
+        else if (WCr == 1) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1, false>), grid_m, dim3(MT), smem_m, st_mid, ta);
+        else if (quad) hipLaunchKernelGGL((splat_mid_kernel<MODE, WCM, true>), grid_m, dim3(MT), smem_m, st_mid, ta);
+        else hipLaunchKernelGGL((splat_mid_kernel<MODE, WCM, false>), grid_m, dim3(MT), smem_m, st_mid, ta);
         TSP_HIP(hipGetLastError());
     }
     TSP_HIP(hipEventRecord(ctx->ev[5], st_mid));
