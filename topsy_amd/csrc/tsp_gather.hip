@@ -795,8 +795,6 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
         } else {                                // kernel H2 (row-uniform gather): 64 px <= P < p_mega
             if (second_channel) rc = launch_huge2<MODE, 2, 1, 16, 4>(ctx, ta, n_huge);
             else if (ctx->huge_variant == 2) rc = launch_huge2<MODE, 1, 1, 32, 4>(ctx, ta, n_huge);
-            else if (ctx->huge_variant == 3) rc = launch_huge2<MODE, 1, 2, 16, 4>(ctx, ta, n_huge);
-            else if (ctx->huge_variant == 4) rc = launch_huge2<MODE, 1, 2, 16, 5>(ctx, ta, n_huge);
             else rc = launch_huge2<MODE, 1, 1, 16, 6>(ctx, ta, n_huge);   // 64x16 strips at 6 waves/SIMD: 17.3 ms against 18.6 for 64x32 at 4
         }
         if (rc) return rc;
