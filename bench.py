@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (f32 in, f32 accumulate)
 B_ALG = {"density": 20, "weighted": 24, "rgb": 28}     # algorithmic bytes/particle
 
 
@@ -176,12 +177,15 @@ def main():
     # HBM bytes of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE doubled as
     # MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); null when no profile matches this workload
     traffic = None
+    mfma_per_launch = None      # v_mfma_f32_32x32x2_f32 instructions of kernel H3 per launch (PMC SQ_INSTS_MFMA)
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "latest_bench_counters.json")))
         if prof.get("bench_line", {}).get("config", {}).get("workload") == workload_name:
             for k, v in prof["per_kernel"].items():
                 if dom in k:
                     traffic = (v.get("hbm_read_bytes_corrected", 0.0) + v.get("hbm_write_bytes", 0.0)) / 1e9
+                if "splat_mega_kernel" in k and v.get("SQ_INSTS_MFMA"):
+                    mfma_per_launch = v["SQ_INSTS_MFMA"]
     except Exception:
         pass
     result = {
@@ -202,6 +206,12 @@ def main():
         "kernel_ms": means,
         "setup_s": t_setup,
     }
+    if mfma_per_launch and means["mega"] > 0:
+        # the matrix-core kernel against ITS roofline: instruction count from the committed PMC pass, duration live
+        tflops = mfma_per_launch * 2 * 32 * 32 * 2 / (means["mega"] * 1e-3) / 1e12
+        result["roofline_mega"] = {"bound": "mfma", "kernel": "splat_mega_kernel", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS, "kernel_ms": means["mega"],
+                                   "mfma_instructions_per_launch": mfma_per_launch}
     if args.h_cap_px <= 0 and world == 1 and not args.generic:
         # the same positions with footprints capped at 8 px isolate the streaming
         # regime (kernel S only); reported next to the headline, never as `value`
