@@ -493,6 +493,13 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 #pragma unroll
                 for (int w = 0; w < W; ++w) nxt[w] = pair_at(w, r_off + 2 * PT_STRIDE * 4);
             };
+            // DPP hazard (gfx9: a VGPR written by a VALU instruction may not be read as a DPP operand in the next two issue
+            // slots).  The DPP operands below are the row factors: they come from LDS (no VALU write) long before their use,
+            // and the compiler does not see inside the asm statements, so pin them in registers here and leave two wait
+            // states; the other operands of the DPP FMAs (top, bot) are ordinary sources and carry no such restriction.
+#pragma unroll
+            for (int k = 0; k < NG; ++k) asm volatile("" : "+v"(rowf[k].x), "+v"(rowf[k].y));
+            asm volatile("s_nop 1");
 #define TSP_H2_ROW(K, T)                                                                                       \
             {                                                                                                  \
                 constexpr int ty_ = 4 * (K) + (T);                                                             \
