@@ -352,7 +352,6 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     const int myrow = lane & (HR - 1);
     const bool rowlane = lane < HR;
     const float pyc_own = (sy + myrow < R) ? (float)(sy + myrow) + 0.5f : __builtin_inff();
-    const float pyc_prev = pyc_own - 1.0f;                 // centre of the row above (exact; +inf stays +inf)
 
     // float32 accumulators hold at most FOLD_EVERY footprints (rounding error ~ sqrt(n) * 2^-24 relative: < 2e-6 at
     // the worst pixel), then go to the float64 render target; second-level register totals (as kernel H keeps) would
@@ -367,6 +366,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     int since_fold = 0;
     const char *PTb = reinterpret_cast<const char *>(PT);
     __syncthreads();                                       // the only workgroup barrier: from here on the waves run free
+    if (sx >= R || sy >= R) return;                        // a strip wholly outside the image (R not a multiple of the tile)
 
     // Every wave scans the workgroup's share of the record list on its own, 64 records at a time (one per lane),
     // and keeps those whose square and disc reach ITS strip -- no shared queue, so no wave ever waits for another.
@@ -431,8 +431,9 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
                 const float f0 = __builtin_floorf(tv);
                 const float fr = (tv - f0) * cv;
                 const int r = (int)f0;
-                const float vp = ((pyc_prev - pcy) + half) * invP;
-                const int rprev = (int)__builtin_floorf(__builtin_amdgcn_fmed3f(__builtin_fmaf(vp, 64.0f, -0.5f), 0.0f, 63.0f));
+                // texel row of the pixel row above = the value of the lane before (v_mov_b32_dpp wave_shr:1); lane 0 and
+                // row 0 of the second half are excluded by `myrow > 0` below
+                const int rprev = __builtin_amdgcn_mov_dpp(r, 0x138, 0xf, 0xf, false);
                 r512 = r * (PT_STRIDE * 4);
                 asm volatile("" ::: "memory");          // (in-order LDS: the previous footprint's table reads are done)
                 if (rowlane) rt[myrow] = make_float2(fr, cv - fr);
@@ -523,7 +524,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             // skipped.  (Laying the change out of line as the unlikely path measured slower: this kernel serves the
             // footprints below p_mega, whose texel rows change every 1-8 pixel rows.)
 #define TSP_H2_GROUP(K)                                                                                        \
-            if ((K) < NG && ((covmask >> (4 * (K))) & 15u) != 0u) { TSP_H2_ROW(K, 0) TSP_H2_ROW(K, 1) TSP_H2_ROW(K, 2) TSP_H2_ROW(K, 3) }
+            if constexpr ((K) < NG) { if (((covmask >> (4 * (K))) & 15u) != 0u) { TSP_H2_ROW(K, 0) TSP_H2_ROW(K, 1) TSP_H2_ROW(K, 2) TSP_H2_ROW(K, 3) } }
             TSP_H2_GROUP(0) TSP_H2_GROUP(1) TSP_H2_GROUP(2) TSP_H2_GROUP(3)
             TSP_H2_GROUP(4) TSP_H2_GROUP(5) TSP_H2_GROUP(6) TSP_H2_GROUP(7)
 #undef TSP_H2_GROUP
@@ -644,6 +645,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
     int since_fold = 0;
     const char *PTb = reinterpret_cast<const char *>(PT);
     __syncthreads();                                       // the only workgroup barrier
+    if (sx >= R || sy >= R) return;                        // a strip wholly outside the image (last_row would be negative)
 
     auto flush = [&]() {
         double *img = a.img + ((size_t)(sy + 4 * kh) * R + (sx + li)) * C;
