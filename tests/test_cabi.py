@@ -52,3 +52,15 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "liboracle" not in src and "oracle/" not in src.replace("the CPU oracle under oracle/", ""), f
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """TOPSY_SPLAT_LIB points the binding at another build; a path with no library must raise, not fall back."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['TOPSY_SPLAT_LIB'] = %r\n"
+            "from topsy_amd import _native\n"
+            "try:\n    _native.load_library()\nexcept _native.BackendUnavailable as e:\n    print('UNAVAILABLE', e)\n"
+            % (ROOT, str(tmp_path / "libmissing.so")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "UNAVAILABLE" in out.stdout and "libmissing.so" in out.stdout, out.stdout + out.stderr
