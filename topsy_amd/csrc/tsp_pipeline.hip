@@ -34,20 +34,33 @@ namespace tsp {
 // ---------------------------------------------------------------------------------------------
 // block-wide helpers (256 threads = 4 waves)
 // ---------------------------------------------------------------------------------------------
+// Wave-wide reductions and scans on the VALU's DPP path (row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15
+// and row_bcast:31 across the rows): kernel S does ten of them per 512-particle chunk, and as __shfl (ds_bpermute_b32) they
+// were 40 % of its LDS instructions -- on the pipe its LDS atomics need.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_or(int identity, int v) {
+    return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);     // lanes without a source get `identity`
+}
+template <typename Op> __device__ __forceinline__ int wave_scan_bits(int v, int identity, Op op) {
+    v = op(v, dpp_or<0x111, 0xf>(identity, v));     // row_shr:1
+    v = op(v, dpp_or<0x112, 0xf>(identity, v));     // row_shr:2
+    v = op(v, dpp_or<0x114, 0xf>(identity, v));     // row_shr:4
+    v = op(v, dpp_or<0x118, 0xf>(identity, v));     // row_shr:8
+    v = op(v, dpp_or<0x142, 0xa>(identity, v));     // row_bcast:15 into rows 1 and 3
+    v = op(v, dpp_or<0x143, 0xc>(identity, v));     // row_bcast:31 into rows 2 and 3
+    return v;                                       // inclusive scan; lane 63 holds the reduction
+}
 __device__ __forceinline__ float wave_min(float v) {
-    for (int o = 32; o; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
+    const int r = wave_scan_bits(__float_as_int(v), __float_as_int(__builtin_inff()),
+                                 [](int a, int b) { return __float_as_int(fminf(__int_as_float(a), __int_as_float(b))); });
+    return __int_as_float(__builtin_amdgcn_readlane(r, 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-    for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    const int r = wave_scan_bits(__float_as_int(v), __float_as_int(-__builtin_inff()),
+                                 [](int a, int b) { return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b))); });
+    return __int_as_float(__builtin_amdgcn_readlane(r, 63));
 }
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
+__device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/) {
+    return wave_scan_bits(v, 0, [](int a, int b) { return a + b; });
 }
 
 struct StreamArgs {
