@@ -802,7 +802,7 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
             else if (second_channel) rc = launch_huge<MODE, 2, 4>(ctx, ta, smem_h, n_huge);
             else rc = launch_huge<MODE, 1, 4>(ctx, ta, smem_h, n_huge);   // 4x8 px/lane measured slower (spills, larger tiles)
         } else {                                // kernel H2 (row-uniform gather): 64 px <= P < p_mega
-            if (second_channel) rc = launch_huge2<MODE, 2, 1, 16, 4>(ctx, ta, n_huge);
+            if (second_channel) rc = launch_huge2<MODE, 2, 1, 16, 4>(ctx, ta, n_huge);      // 5-6 waves/SIMD spill: 21 / 31 vs 16 ms
             else if (ctx->huge_variant == 2) rc = launch_huge2<MODE, 1, 1, 32, 4>(ctx, ta, n_huge);
             else rc = launch_huge2<MODE, 1, 1, 16, 6>(ctx, ta, n_huge);   // 64x16 strips at 6 waves/SIMD: 17.3 ms against 18.6 for 64x32 at 4
         }
@@ -811,7 +811,7 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
     TSP_HIP(hipEventRecord(ctx->ev[10], st));
     if (n_mega > 0) {                           // kernel H3 (matrix cores): P >= p_mega, the tail end of the huge list
         ta.geom = mega_geom; ta.w = mega_w; ta.n_records = n_mega;
-        if (second_channel) rc = launch_mega<MODE, 2, 2, 3>(ctx, ta, n_mega);
+        if (second_channel) rc = launch_mega<MODE, 2, 2, 4>(ctx, ta, n_mega);      // 64 accumulator registers at 4 waves/SIMD (3: 10.2 vs 9.9 ms)
         else rc = launch_mega<MODE, 1, 2, 4>(ctx, ta, n_mega);   // 4 column blocks per strip and 5-6 waves/SIMD measured no faster
         if (rc) return rc;
     }
