@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
     constexpr int WIN = WinSize<WC>::value;
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
     double *win = smem_d;                                            // [WC][WIN*WIN]
-    float *T3 = reinterpret_cast<float *>(win + WC * WIN * WIN);     // mip level 3: 8x8
+    float *T23 = reinterpret_cast<float *>(win + WC * WIN * WIN);    // mip levels 2 (16x16) and 3 (8x8): 320 floats
     __shared__ float s_red[4][4], s_mbb[4][4];
     __shared__ int s_cnt[4][2];
     __shared__ long long s_base[2];
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
     const Camera &cam = a.cam;
     const int R = cam.R;
     for (int i = tid; i < WC * WIN * WIN; i += 256) win[i] = 0.0;
-    if (tid < 64) T3[tid] = a.mips[5376 + tid];
+    for (int i = tid; i < 320; i += 256) T23[i] = a.mips[5120 + i];
     __syncthreads();
 
     // window state (uniform): origin and the dirty rectangle (window coordinates, inclusive)
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
                     cover_range(pr.pcx, pr.half, R, ilo, ihi);
                     cover_range(pr.pcy, pr.half, R, jlo, jhi);
                     vis = (ilo <= ihi) && (jlo <= jhi);
-                    // a small footprint covers <= 12 pixels per axis and R <= 16384: both fit 16 bits
+                    // a small footprint covers <= 23 pixels per axis and R <= 16384: both fit 16 bits
                     xr[k] = ilo | (min(ihi - ilo + 1, 0xffff) << 16);
                     yr[k] = jlo | (min(jhi - jlo + 1, 0xffff) << 16);
                 }
@@ -282,14 +282,16 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
             const float half = 0.5f * PP[k], invP = 1.0f / PP[k];
             const int ilo = xr[k] & 0xffff, ihi = ilo + (xr[k] >> 16) - 1;
             const int jlo = yr[k] & 0xffff, jhi = jlo + (yr[k] >> 16) - 1;
+            // mip 3 up to 11.3 px, mip 2 up to 22.6 px (p_small may reach that far)
+            const int n = PP[k] > P_L2 ? 16 : 8, toff = PP[k] > P_L2 ? 0 : 256;
             for (int j = jlo; j <= jhi; ++j) {
                 const float dy = ((float)j + 0.5f) - pcy[k];
-                const int ty = nearest_index((dy + half) * invP, 8);
+                const int ty = toff + nearest_index((dy + half) * invP, n) * n;
                 double *drow = win + (j - woy) * WIN - wox;
                 for (int i = ilo; i <= ihi; ++i) {
                     const float dx = ((float)i + 0.5f) - pcx[k];
-                    const int tx = nearest_index((dx + half) * invP, 8);
-                    const float kv = T3[ty * 8 + tx];
+                    const int tx = nearest_index((dx + half) * invP, n);
+                    const float kv = T23[ty + tx];
                     double *d = drow + i;
                     if (MODE == TSP_MODE_RGB) {
                         latomic_add(d, kv * w0[k]); latomic_add(d + WIN * WIN, kv * w1[k]);
@@ -691,7 +693,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     const bool second_channel = (MODE == TSP_MODE_DEPTH) || (MODE == TSP_MODE_RGB) || (ctx->p.q != nullptr && ctx->use_quantity);
     const int WCr = (MODE == TSP_MODE_RGB) ? 4 : (second_channel ? 2 : 1);
     const int WIN = (WCr == 1) ? WinSize<1>::value : WinSize<C>::value;
-    const size_t smem_s = (size_t)WCr * WIN * WIN * sizeof(double) + 64 * sizeof(float);
+    const size_t smem_s = (size_t)WCr * WIN * WIN * sizeof(double) + 320 * sizeof(float);
     constexpr int WCM = (MODE == TSP_MODE_RGB) ? 3 : C;      // LDS tile channels of kernel M (rgb: values only)
     const int mth = mtile_h(WCr == 1 ? 1 : WCM);
     // quadrant tables pay where LDS limits the occupancy: rgb (three channels: 2 -> 4 workgroups per CU, 21.0 -> 17.1 ms);
@@ -700,8 +702,8 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     const size_t smem_m = (size_t)(WCr == 1 ? 1 : WCM) * mth * MSTR * sizeof(double) + (quad ? MIPQ_TOTAL : MIP_TOTAL) * sizeof(float) + (size_t)ctx->debug_extra_lds;
     const int mtiles_y = (ctx->R + mth - 1) / mth;
     if (!(ctx->kernel_attr_done & (1u << MODE))) {
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WinSize<C>::value * WinSize<C>::value * sizeof(double) + 256)));
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WinSize<1>::value * WinSize<1>::value * sizeof(double) + 256)));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WinSize<C>::value * WinSize<C>::value * sizeof(double) + 1280)));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WinSize<1>::value * WinSize<1>::value * sizeof(double) + 1280)));
         const int lds_m = (int)((size_t)C * 32 * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, WCM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
