@@ -216,6 +216,9 @@ def main():
         # the same positions with footprints capped at 8 px isolate the streaming
         # regime (kernel S only); reported next to the headline, never as `value`
         result["bandwidth_regime"] = hcapped_line(args, ctx, n_total, n_per, rank, M, sf, mode, measured_peak)
+        if args.mode == "density":
+            # BASELINE.json configs[1] beside the headline: 1e7 particles, density-weighted quantity, 1024^2, one GPU
+            result["baseline_config_1"] = config1_line(args, ctx, M, sf)
     if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(args, n_total, M, sf, R)
     print(json.dumps(result), flush=True)
@@ -245,6 +248,24 @@ def hcapped_line(args, ctx, n_total, n_per, rank, M, sf, mode, measured_peak, ca
             "value": n_per / (float(np.mean(ms)) * 1e-3), "unit": "particles/s", "fragments_per_particle": frags / n_per,
             "stream_kernel_ms": float(np.mean(st)), "stream_kernel_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
             "frac_of_measured_read_peak": gbps / measured_peak}
+
+
+def config1_line(args, ctx, M, sf, n=10_000_000, frames=5):
+    """10M particles with the reference's synthetic quantity (stand-in for gas + temp), weighted render."""
+    from topsy_amd import _native
+    from topsy_amd.particle_buffers import ParticleBuffers
+    ctx.generate_synthetic(n, first=0, count=n, seed=1337, h_cap=0.0, with_quantity=True, with_rgb=False)
+    if not args.no_reorder:
+        ctx.reorder_spatial(ParticleBuffers._num_strata(n), 1337)
+    ms = []
+    for i in range(frames + 1):
+        t = ctx.render(M, sf, clear=True, mode=_native.MODE_WEIGHTED)
+        if i:
+            ms.append(t)
+    st = ctx.stats()
+    return {"workload": f"{n:.3g} particles, density-weighted quantity, {args.resolution}^2 buffer, camera A, reference h-law",
+            "ms_per_step": float(np.mean(ms)), "value": n / (float(np.mean(ms)) * 1e-3), "unit": "particles/s",
+            "kernel_ms": {"stream": st["ms_stream"], "mid": st["ms_mid"], "huge": st["ms_huge"], "mega": st["ms_mega"]}}
 
 
 def cpu_baseline(args, n_total, M, sf, R):
