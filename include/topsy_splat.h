@@ -86,6 +86,13 @@ int tsp_upload_particles(tsp_context *ctx, int64_t n, const float *x, const floa
  * quantity swap: src/topsy/visualizer.py:294-309). */
 int tsp_upload_quantity(tsp_context *ctx, const float *q);
 int tsp_upload_rgb(tsp_context *ctx, const float *r, const float *g, const float *b);
+/* The same three channels computed ON the device from SSP band magnitudes -- the 3 x n_bands "band contraction" of the
+ * rgb render mode: channel_c[i] = sum_b weights[c * n_bands + b] * 10^(-0.4 * mags[b * n + i]), NaN -> 0, evaluated in
+ * float64 and rounded to float32 once.  With weights = diag(0.5, 1, 1) over the bands (I, V, U) this is the reference's
+ * PynbodyDataInMemory.get_rgb_masses / _effective_mass_for_band (src/topsy/loader.py:112-121).  mags: n_bands arrays of n
+ * float64 each, contiguous, caller's particle order.  An HBM-bound VALU kernel (8 n_bands bytes in, 12 bytes out and
+ * 3 n_bands FMAs per particle): the matrix cores have nothing to gain here. */
+int tsp_upload_band_magnitudes(tsp_context *ctx, int n_bands, const double *mags, const double *weights);
 
 /* On-device synthetic snapshot = restatement of topsy.loader.TestDataLoader's distribution
  * (reference src/topsy/loader.py:241-332) with a counter-based generator, so that shard

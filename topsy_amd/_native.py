@@ -52,6 +52,7 @@ SIGNATURES = {
     "tsp_upload_particles": (ctypes.c_int, [_ctx, ctypes.c_int64, _fp, _fp, _fp, _fp, _fp]),
     "tsp_upload_quantity": (ctypes.c_int, [_ctx, _fp]),
     "tsp_upload_rgb": (ctypes.c_int, [_ctx, _fp, _fp, _fp]),
+    "tsp_upload_band_magnitudes": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "tsp_generate_synthetic": (ctypes.c_int, [_ctx, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64,
                                               ctypes.c_float, ctypes.c_int, ctypes.c_int]),
     "tsp_reorder_spatial": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_uint64, _i64p]),
@@ -182,6 +183,16 @@ class Context:
         n = self.num_particles
         r, g, b = _f32(r, n, "r"), _f32(g, n, "g"), _f32(b, n, "b")
         _check(self._lib.tsp_upload_rgb(self._h, _ptr(r), _ptr(g), _ptr(b)))
+
+    def upload_band_magnitudes(self, mags, weights):
+        """rgb channels from SSP band magnitudes on the device: channel_c = sum_b weights[c, b] * 10^(-0.4 * mags[b]).
+        mags: (n_bands, n) float64; weights: (3, n_bands) float64 (reference loader.py:112-121: diag(0.5, 1, 1) over I, V, U)."""
+        mags = np.ascontiguousarray(mags, dtype=np.float64)
+        weights = np.ascontiguousarray(weights, dtype=np.float64)
+        if mags.ndim != 2 or mags.shape[1] != self.num_particles or weights.shape != (3, mags.shape[0]):
+            raise ValueError("mags must be (n_bands, n_particles) and weights (3, n_bands)")
+        dp = ctypes.POINTER(ctypes.c_double)
+        _check(self._lib.tsp_upload_band_magnitudes(self._h, mags.shape[0], mags.ctypes.data_as(dp), weights.ctypes.data_as(dp)))
 
     def generate_synthetic(self, n_total, first=0, count=None, seed=1337, h_cap=0.0, with_quantity=False,
                            with_rgb=False):

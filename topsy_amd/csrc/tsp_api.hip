@@ -249,6 +249,48 @@ int tsp_upload_rgb(tsp_context *ctx, const float *r, const float *g, const float
     return TSP_OK;
 }
 
+// one lane per particle; the magnitudes are read in the caller's order (through the load-time permutation, if any)
+__global__ __launch_bounds__(256) void band_contraction_kernel(const double *__restrict__ mags, const double *__restrict__ weights,
+                                                               int n_bands, int64_t n, const uint32_t *__restrict__ perm,
+                                                               float *__restrict__ r, float *__restrict__ g, float *__restrict__ b) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t src = perm ? (int64_t)perm[i] : i;
+        double acc[3] = {0.0, 0.0, 0.0};
+        for (int k = 0; k < n_bands; ++k) {
+            const double lum = pow(10.0, -0.4 * mags[(int64_t)k * n + src]);      // _effective_mass_for_band (loader.py:112-113)
+            for (int c = 0; c < 3; ++c) {
+                const double w = weights[c * n_bands + k];
+                if (w != 0.0) acc[c] += w * lum;
+            }
+        }
+        const float fr = (float)acc[0], fg = (float)acc[1], fb = (float)acc[2];
+        r[i] = (fr != fr) ? 0.0f : fr;                                            // rgb[np.isnan(rgb)] = 0 (loader.py:120)
+        g[i] = (fg != fg) ? 0.0f : fg;
+        b[i] = (fb != fb) ? 0.0f : fb;
+    }
+}
+
+int tsp_upload_band_magnitudes(tsp_context *ctx, int n_bands, const double *mags, const double *weights) {
+    TSP_REQUIRE(ctx && mags && weights, TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(n_bands >= 1 && n_bands <= 64, TSP_EINVAL, "n_bands %d out of range", n_bands);
+    TSP_REQUIRE(ctx->p.n > 0, TSP_ESTATE, "upload particles before the band magnitudes");
+    TSP_HIP(hipSetDevice(ctx->device));
+    const int64_t n = ctx->p.n;
+    DeviceScratch d_mags, d_w;
+    TSP_HIP(d_mags.alloc((size_t)n_bands * n * sizeof(double)));
+    TSP_HIP(d_w.alloc((size_t)3 * n_bands * sizeof(double)));
+    TSP_HIP(hipMemcpyAsync(d_mags.p, mags, (size_t)n_bands * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    TSP_HIP(hipMemcpyAsync(d_w.p, weights, (size_t)3 * n_bands * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int rc;
+    if ((rc = ensure_array(&ctx->p.r, n)) || (rc = ensure_array(&ctx->p.g, n)) || (rc = ensure_array(&ctx->p.b, n))) return rc;
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 16);
+    hipLaunchKernelGGL(band_contraction_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_mags.as<double>(), d_w.as<double>(), n_bands, n,
+                       ctx->p.perm, ctx->p.r, ctx->p.g, ctx->p.b);
+    TSP_HIP(hipGetLastError());
+    TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
 int tsp_generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int64_t count, uint64_t seed, float h_cap,
                            int with_quantity, int with_rgb) {
     TSP_REQUIRE(ctx, TSP_EINVAL, "NULL context");

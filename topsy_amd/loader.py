@@ -162,14 +162,19 @@ class ArrayDataLoader(AbstractDataLoader):
     """Particles given as numpy arrays (e.g. pulled from a pynbody snapshot by the caller:
     snap['pos'], snap['smooth'], snap['mass'], ...; reference PynbodyDataInMemory, loader.py:79-154)."""
 
+    # reference PynbodyDataInMemory.get_rgb_masses (loader.py:115-121): (band, weight) per rgb channel
+    RGB_BANDS = (("I", 0.5), ("V", 1.0), ("U", 1.0))
+
     def __init__(self, device=None, pos=None, smooth=None, mass=None, quantities=None, rgb=None,
-                 units="kpc", periodicity_scale=None, with_cells=False):
+                 units="kpc", periodicity_scale=None, with_cells=False, band_magnitudes=None):
         super().__init__(device)
         self._pos = np.asarray(pos, dtype=np.float32)
         self._smooth = np.asarray(smooth, dtype=np.float32)
         self._mass = np.asarray(mass, dtype=np.float32)
         self._quantities = {k: np.asarray(v, dtype=np.float32) for k, v in (quantities or {}).items()}
         self._rgb = None if rgb is None else np.asarray(rgb, dtype=np.float32)
+        # SSP magnitudes per band (snap['I_mag'], ...): the rgb masses derive from them, on the device when rendered
+        self._mags = None if band_magnitudes is None else {k: np.asarray(v, dtype=np.float64) for k, v in band_magnitudes.items()}
         self._units = units
         self._period = periodicity_scale
         if not (len(self._pos) == len(self._smooth) == len(self._mass)):
@@ -185,6 +190,8 @@ class ArrayDataLoader(AbstractDataLoader):
             self._quantities = {k: v[order] for k, v in self._quantities.items()}
             if self._rgb is not None:
                 self._rgb = self._rgb[order]
+            if self._mags is not None:
+                self._mags = {k: v[order] for k, v in self._mags.items()}
 
     def __len__(self):
         return len(self._pos)
@@ -208,9 +215,23 @@ class ArrayDataLoader(AbstractDataLoader):
         return "density" if quantity_name is None else quantity_name
 
     def get_rgb_masses(self):
-        if self._rgb is None:
+        if self._rgb is not None:
+            return self._rgb
+        if self._mags is None:
             raise KeyError("no rgb band masses were supplied")
-        return self._rgb
+        # _effective_mass_for_band / get_rgb_masses of the reference (loader.py:112-121), on the host
+        rgb = np.empty((len(self), 3), dtype=np.float32)
+        for c, (band, weight) in enumerate(self.RGB_BANDS):
+            rgb[:, c] = (10 ** (-0.4 * self._mags[band])) * weight
+        rgb[np.isnan(rgb)] = 0.0
+        return rgb
+
+    def get_band_magnitudes(self):
+        """(mags (3, n) float64, weights (3, 3) float64) for the device-side contraction (tsp_upload_band_magnitudes), or None."""
+        if self._rgb is not None or self._mags is None:
+            return None
+        mags = np.stack([self._mags[band] for band, _ in self.RGB_BANDS])
+        return mags, np.diag([w for _, w in self.RGB_BANDS]).astype(np.float64)
 
     def get_position_units(self):
         return self._units

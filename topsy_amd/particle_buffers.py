@@ -81,6 +81,12 @@ class ParticleBuffers:
 
     def ensure_rgb(self):
         if not self._have_rgb:
+            bands = getattr(self._loader, "get_band_magnitudes", lambda: None)()
+            if bands is not None:
+                logger.info("Contracting band magnitudes to rgb on the device")
+                self.context.upload_band_magnitudes(*bands)
+                self._have_rgb = True
+                return
             logger.info("Uploading rgb arrays")
             rgb = np.asarray(self._loader.get_rgb_masses(), dtype=np.float32)
             rgb = np.where(np.isnan(rgb), np.float32(0.0), rgb)      # reference loader.py:120
