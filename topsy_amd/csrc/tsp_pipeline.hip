@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
         dx0 = WIN; dy0 = WIN; dx1 = -1; dy1 = -1;
     };
 
-    for (int c = c_begin; c < c_end; ++c) {
-        // ---- locate the chunk: range r, particles [first, first + cnt) -------------------------
+    // locate chunk c: range r, particles [first, first + cnt)
+    auto locate = [&](int c, int64_t &first, int &cnt) {
         int r = 0;
         if (a.n_ranges > 1) {
             int lo = 0, hi = a.n_ranges - 1;
@@ -146,8 +146,31 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
             r = lo;
         }
         const int64_t in_range = (int64_t)(c - cprefix[r]) * CHUNK;
-        const int64_t first = starts[r] + in_range;
-        const int cnt = (int)min((int64_t)CHUNK, lens[r] - in_range);
+        first = starts[r] + in_range;
+        cnt = (int)min((int64_t)CHUNK, lens[r] - in_range);
+    };
+    // The attributes of a chunk are loaded one chunk AHEAD: the loads of chunk c + 1 are issued when chunk c has been
+    // classified and are in flight while it is rasterised (the kernel is latency-bound: 60 % of its wave time was s_waitcnt).
+    constexpr int NATTR = (MODE == TSP_MODE_RGB) ? 7 : 6;      // x y z h + (m, q) or (r, g, b)
+    float L[KPT][NATTR];
+    auto load_chunk = [&](int64_t first, int cnt) {
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int li = k * 256 + tid;
+#pragma unroll
+            for (int t = 0; t < NATTR; ++t) L[k][t] = 0.0f;
+            if (li < cnt) {
+                const int64_t i = first + li;
+                L[k][0] = a.p.x[i]; L[k][1] = a.p.y[i]; L[k][2] = a.p.z[i]; L[k][3] = a.p.h[i];
+                if (MODE == TSP_MODE_RGB) { L[k][4] = a.p.r[i]; L[k][5] = a.p.g[i]; L[k][6] = a.p.b[i]; }
+                else { L[k][4] = a.p.m[i]; L[k][5] = (MODE != TSP_MODE_DEPTH && a.p.q) ? a.p.q[i] : 0.0f; }
+            }
+        }
+    };
+    int64_t first = 0, first_next = 0;
+    int cnt = 0, cnt_next = 0;
+    if (c_begin < c_end) { locate(c_begin, first, cnt); load_chunk(first, cnt); }
+    for (int c = c_begin; c < c_end; ++c) {
 
         // ---- phase 1: coalesced loads, projection, classification ------------------------------
         float pcx[KPT], pcy[KPT], PP[KPT], w0[KPT], w1[KPT], w2[KPT];
@@ -163,9 +186,8 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
             pcx[k] = pcy[k] = PP[k] = w0[k] = w1[k] = w2[k] = 0.0f;
             xr[k] = yr[k] = 0;
             if (li < cnt) {
-                const int64_t i = first + li;
-                const float h = a.p.h[i];
-                const Proj pr = project(cam, a.p.x[i], a.p.y[i], a.p.z[i], h);
+                const float h = L[k][3];
+                const Proj pr = project(cam, L[k][0], L[k][1], L[k][2], h);
                 bool vis = false;
                 if (pr.keep) {
                     // any pixel centre covered?  (exact test via the canonical interval)
@@ -180,10 +202,10 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
                 if (vis) {
                     const float hh = h * h;
                     if (MODE == TSP_MODE_RGB) {
-                        w0[k] = a.p.r[i] / hh; w1[k] = a.p.g[i] / hh; w2[k] = a.p.b[i] / hh;
+                        w0[k] = L[k][4] / hh; w1[k] = L[k][5] / hh; w2[k] = L[k][6] / hh;
                     } else {
-                        w0[k] = a.p.m[i] / hh;
-                        w1[k] = (MODE == TSP_MODE_DEPTH) ? pr.cz : (a.p.q ? a.p.q[i] : 0.0f);
+                        w0[k] = L[k][4] / hh;
+                        w1[k] = (MODE == TSP_MODE_DEPTH) ? pr.cz : L[k][5];
                     }
                     pcx[k] = pr.pcx; pcy[k] = pr.pcy; PP[k] = pr.P;
                     if (pr.P < a.p_small) {
@@ -204,6 +226,9 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
                 }
             }
         }
+
+        // the next chunk's attributes start to load now; phases 2 - 5 of this chunk hide their latency
+        if (c + 1 < c_end) { locate(c + 1, first_next, cnt_next); load_chunk(first_next, cnt_next); }
 
         // ---- phase 2: the chunk's small-footprint bounding box places the LDS window (uniform) ------
         // (each exchange has its own LDS scratch, so one barrier per exchange suffices: the barriers of
@@ -275,7 +300,7 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
         __syncthreads();
         const long long mid_base = s_base[0], huge_base = s_base[1];
 
-        // ---- phase 4: rasterise small footprints (one lane per particle, mip 3 nearest) ---------
+        // ---- phase 4: rasterise small footprints (one lane per particle, mips 3 / 2 nearest) -----
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             if (cls[k] != CLS_SMALL || !a.emit_small) continue;
@@ -341,6 +366,7 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
                 }
             }
         }
+        first = first_next; cnt = cnt_next;
     }
     __syncthreads();
     flush();
