@@ -16,7 +16,12 @@ index range; the only collective is the image reduce.
 
 Prints ONE JSON line on rank 0 with the contract's keys plus `roofline` (dominant kernel, timed
 with hipEvents on the stream it runs on) and `cpu_baseline` (the CPU oracle, kind "port", on a
-bounded uniform sample of the same snapshot on the host cores).
+bounded uniform sample of the same snapshot on the host cores).  At N = 1 the line also carries
+driver-timed extras: the h-capped bandwidth regime, BASELINE configs[1] (1e7 weighted), configs[2] at
+exactly 1e8, configs[4] (5e7 rgb, 2048^2) and the whole 1e9-particle snapshot of configs[3] resident on one GPU.
+
+At N = 1 the process never imports torch (north_star: no PyTorch on this path); torch.distributed is used at
+N > 1 only, as the launcher's rendezvous for the 128-byte RCCL id, the barrier and the max-over-ranks time.
 """
 import argparse
 import json
@@ -29,16 +34,18 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (f32 in, f32 accumulate)
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_MEASURED_COPY_GBPS = 6290.0 # MI355X_MICROARCH.md: 6.29 TB/s measured (float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, 64 FLOP/clk/SIMD
 B_ALG = {"density": 20, "weighted": 24, "rgb": 28}     # algorithmic bytes/particle
+KERNELS = ("stream", "mid", "huge", "mega")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--particles-per-gpu", type=float, default=1.25e8)
     ap.add_argument("--resolution", type=int, default=1024)
     ap.add_argument("--scale", type=float, default=200.0)
@@ -49,7 +56,42 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--generic", action="store_true", help="use the generic (global-atomic) kernel")
     ap.add_argument("--no-reorder", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline frames: no extra configurations, no CPU baseline (what the profiler runs, so "
+                         "that every kernel instance in a profile belongs to the headline workload)")
     return ap.parse_args()
+
+
+def camera(scale):
+    """camera A (reference default view): identity rotation, zero offset"""
+    M = np.eye(4, dtype=np.float32)
+    M[:3, :3] /= scale
+    M[2, :] = [0.0, 0.0, 0.5 / scale, 0.5]
+    return M, np.float32(1.0 / scale)
+
+
+def num_strata(n):
+    from topsy_amd.particle_buffers import ParticleBuffers
+    return ParticleBuffers._num_strata(n)
+
+
+def profile_entry(prof, kernel, mode):
+    """The PMC entry of `kernel` for the instantiation the headline frames run (MODE, channels = the first two
+    template arguments): exactly one key may match, else None -- never 'the last one that contains the name'."""
+    tmpl_mode = 2 if mode == "rgb" else 0
+    first = {"density": "1", "weighted": "2", "rgb": None}[mode]
+    hits = []
+    for k, v in prof.get("per_kernel", {}).items():
+        name, _, args = k.partition("<")
+        if name.split("::")[-1] != kernel:
+            continue
+        a = [x.strip() for x in args.rstrip(">").split(",")]
+        if not a or a[0] != str(tmpl_mode):
+            continue
+        if first is not None and (len(a) < 2 or a[1] != first):
+            continue
+        hits.append((k, v))
+    return hits[0] if len(hits) == 1 else (None, None)
 
 
 def main():
@@ -62,9 +104,9 @@ def main():
             sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
         args.gpus = world
 
-    import torch
-    dist = None
+    dist = torch = None
     if world > 1:
+        import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -76,14 +118,14 @@ def main():
     n_total = n_per * world
     mode = {"density": _native.MODE_WEIGHTED, "weighted": _native.MODE_WEIGHTED, "rgb": _native.MODE_RGB}[args.mode]
     ctx = _native.Context(R, 4 if args.mode == "rgb" else 2, device_id=local_rank)
-    ctx.set_kernel_mips(kernel_lut.kernel_mips())
+    mips = kernel_lut.kernel_mips()
+    ctx.set_kernel_mips(mips)
     h_cap = args.h_cap_px * args.scale / (2.0 * R) if args.h_cap_px > 0 else 0.0
     t_setup = time.time()
     ctx.generate_synthetic(n_total, first=rank * n_per, count=n_per, seed=1337, h_cap=h_cap,
                            with_quantity=args.mode == "weighted", with_rgb=args.mode == "rgb")
     if not args.no_reorder:
-        from topsy_amd.particle_buffers import ParticleBuffers
-        ctx.reorder_spatial(ParticleBuffers._num_strata(n_per), 1337)       # load-time ordering, as the product path does
+        ctx.reorder_spatial(num_strata(n_per), 1337)       # load-time ordering, as the product path does
     t_setup = time.time() - t_setup
 
     if world > 1:
@@ -91,25 +133,20 @@ def main():
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(world, rank, ids[0])
 
-    # camera A (reference default view): identity rotation, zero offset
-    M = np.eye(4, dtype=np.float32)
-    M[:3, :3] /= args.scale
-    M[2, :] = [0.0, 0.0, 0.5 / args.scale, 0.5]
-    sf = np.float32(1.0 / args.scale)
+    M, sf = camera(args.scale)
     import matplotlib
     lut = matplotlib.colormaps["twilight_shifted"](np.linspace(0.001, 0.999, 1000)).astype(np.float32)
     flags = _native.PIPE_GENERIC if args.generic else _native.PIPE_DEFAULT
 
-    kernel_ms = {"stream": [], "mid": [], "huge": [], "mega": [], "total": [], "reduce": []}
+    kernel_ms = {k: [] for k in KERNELS + ("total", "reduce")}
     vmin, vmax = -12.0, -4.0
 
     def frame(record):
         ctx.render(M, sf, clear=True, mode=mode, flags=flags)
         if record:
             st = ctx.stats()
-            kernel_ms["stream"].append(st["ms_stream"]); kernel_ms["mid"].append(st["ms_mid"])
-            kernel_ms["huge"].append(st["ms_huge"]); kernel_ms["mega"].append(st["ms_mega"])
-            kernel_ms["total"].append(st["ms_total"])
+            for k in KERNELS + ("total",):
+                kernel_ms[k].append(st["ms_" + k])
         if world > 1:
             ms = ctx.comm_reduce_image(root=0)
             if record:
@@ -121,16 +158,21 @@ def main():
         return None
 
     def barrier():
+        # every tsp_* call is synchronous (it returns after its GPU work has completed), so at N = 1 there is nothing
+        # in flight here; at N > 1 the ranks meet and torch's own stream is drained as the contract asks
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         frame(False)
     barrier()
+    step_s = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = frame(True)
+        ts = time.perf_counter()
+        frame(True)
+        step_s.append(time.perf_counter() - ts)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -139,7 +181,7 @@ def main():
         elapsed = float(t.item())
 
     ctx.set_option("count_fragments", 1)
-    ctx.render(M, sf, clear=True, mode=mode, flags=_native.PIPE_GENERIC if args.generic else flags)
+    ctx.render(M, sf, clear=True, mode=mode, flags=flags)
     st = ctx.stats()
     ctx.set_option("count_fragments", 0)
     frags = st["n_fragments"]
@@ -156,9 +198,10 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total / (elapsed / args.steps)
+    ms_median = float(np.median(step_s)) * 1e3
     # dominant kernel of the frame and its roofline (HBM: B_alg bytes/particle streamed once)
     means = {k: float(np.mean(v)) if v else 0.0 for k, v in kernel_ms.items()}
-    parts = {k: means[k] for k in ("stream", "mid", "huge", "mega")}
+    parts = {k: means[k] for k in KERNELS}
     if sum(parts.values()) <= 0.0:
         dom, dom_ms = "splat_generic_kernel", means["total"]
     else:
@@ -173,19 +216,20 @@ def main():
                      f"(scale {args.scale:g}), reference TestDataLoader h-law"
                      + (f", h capped at {args.h_cap_px:g} px" if args.h_cap_px > 0 else "")
                      + ", splat + " + ("RCCL image reduce + " if world > 1 else "") + "colormap")
-    measured_peak = ctx.measure_read_bandwidth(1 << 30, 10)
+    measured_peak = ctx.measure_read_bandwidth(4 << 30, 5)
     # HBM bytes of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE doubled as
     # MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); null when no profile matches this workload
-    traffic = None
-    mfma_per_launch = None      # v_mfma_f32_32x32x2_f32 instructions of kernel H3 per launch (PMC SQ_INSTS_MFMA)
+    traffic = traffic_kernel = None
+    mfma_per_launch = None      # v_mfma_f32_* instructions of kernel H3 per launch (PMC SQ_INSTS_MFMA)
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "latest_bench_counters.json")))
         if prof.get("bench_line", {}).get("config", {}).get("workload") == workload_name:
-            for k, v in prof["per_kernel"].items():
-                if dom in k:
-                    traffic = (v.get("hbm_read_bytes_corrected", 0.0) + v.get("hbm_write_bytes", 0.0)) / 1e9
-                if "splat_mega_kernel" in k and v.get("SQ_INSTS_MFMA"):
-                    mfma_per_launch = v["SQ_INSTS_MFMA"]
+            traffic_kernel, v = profile_entry(prof, dom, args.mode)
+            if v is not None:
+                traffic = (v.get("hbm_read_bytes_corrected", 0.0) + v.get("hbm_write_bytes", 0.0)) / 1e9
+            _, v = profile_entry(prof, "splat_mega_kernel", args.mode)
+            if v is not None and v.get("SQ_INSTS_MFMA"):
+                mfma_per_launch = v["SQ_INSTS_MFMA"]
     except Exception:
         pass
     result = {
@@ -197,10 +241,12 @@ def main():
                    "particles_per_gpu": n_per, "resolution": R, "sharding": f"index-range x{world}",
                    "pipeline": "generic" if args.generic else "four-class (stream / mid scatter / row-uniform gather / MFMA)",
                    "fragments_per_particle": frags / n_total, "frames_per_s": 1e3 / ms_per_step},
+        "ms_per_step_median": ms_median, "value_at_median": n_total / (ms_median * 1e-3),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "GB per launch (PMC)", "kernel_ms": dom_ms,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "GB per launch (PMC)",
+                     "traffic_kernel": traffic_kernel, "kernel_ms": dom_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "measured_read_peak_GBps": measured_peak,
+                     "measured_read_peak_GBps": measured_peak, "guide_measured_copy_GBps": HBM_MEASURED_COPY_GBPS,
                      "stream_kernel_ms": stream_ms,
                      "stream_kernel_GBps": bytes_per_launch / (stream_ms * 1e-3) / 1e9 if stream_ms > 0 else 0.0},
         "kernel_ms": means,
@@ -212,14 +258,34 @@ def main():
         result["roofline_mega"] = {"bound": "mfma", "kernel": "splat_mega_kernel", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS, "kernel_ms": means["mega"],
                                    "mfma_instructions_per_launch": mfma_per_launch}
-    if args.h_cap_px <= 0 and world == 1 and not args.generic:
+    extras = world == 1 and not args.generic and not args.headline_only and args.h_cap_px <= 0
+    if extras:
         # the same positions with footprints capped at 8 px isolate the streaming
         # regime (kernel S only); reported next to the headline, never as `value`
         result["bandwidth_regime"] = hcapped_line(args, ctx, n_total, n_per, rank, M, sf, mode, measured_peak)
-        if args.mode == "density":
-            # BASELINE.json configs[1] beside the headline: 1e7 particles, density-weighted quantity, 1024^2, one GPU
-            result["baseline_config_1"] = config1_line(args, ctx, M, sf)
-    if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
+    if extras and args.mode == "density":
+        # the other single-GPU configurations of BASELINE.json, driver-timed beside the headline (never `value`)
+        result["baseline_config_1"] = config_line(ctx, 10_000_000, "weighted", R, args,
+                                                  "BASELINE.json configs[1]: 1e7 particles, density-weighted quantity")
+        result["baseline_config_2"] = config_line(ctx, 100_000_000, "density", R, args,
+                                                  "BASELINE.json configs[2]: exactly 1e8 dm particles, density")
+        ctx.close()
+        ctx = None
+        c5 = _native.Context(2048, 4, device_id=local_rank)
+        c5.set_kernel_mips(mips)
+        result["baseline_config_4"] = config_line(c5, 50_000_000, "rgb", 2048, args,
+                                                  "BASELINE.json configs[4]: 5e7 star particles, rgb, 2048^2")
+        c5.close()
+        try:
+            c9 = _native.Context(R, 2, device_id=local_rank)
+            c9.set_kernel_mips(mips)
+            result["config_3_on_one_gpu"] = config_line(c9, 1_000_000_000, "density", R, args,
+                                                        "the whole 1e9-particle snapshot of BASELINE.json configs[3] resident on ONE GPU (20 GB)",
+                                                        frames=5)
+            c9.close()
+        except _native.BackendError as e:          # e.g. not enough free HBM on a shared device
+            result["config_3_on_one_gpu"] = {"error": str(e)[:200]}
+    if not args.no_cpu_baseline and not args.headline_only and world == 1:      # reported baseline: rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(args, n_total, M, sf, R)
     print(json.dumps(result), flush=True)
     if dist is not None:
@@ -227,45 +293,59 @@ def main():
         dist.destroy_process_group()
 
 
-def hcapped_line(args, ctx, n_total, n_per, rank, M, sf, mode, measured_peak, cap_px=8.0, frames=5):
+def hcapped_line(args, ctx, n_total, n_per, rank, M, sf, mode, measured_peak, cap_px=8.0, frames=10):
     R = args.resolution
     ctx.generate_synthetic(n_total, first=rank * n_per, count=n_per, seed=1337, h_cap=cap_px * args.scale / (2.0 * R),
                            with_quantity=args.mode == "weighted", with_rgb=args.mode == "rgb")
     if not args.no_reorder:
-        from topsy_amd.particle_buffers import ParticleBuffers
-        ctx.reorder_spatial(ParticleBuffers._num_strata(n_per), 1337)
-    ms, st = [], []
+        ctx.reorder_spatial(num_strata(n_per), 1337)
+    ms, st, mid = [], [], []
     for i in range(frames + 1):
         t = ctx.render(M, sf, clear=True, mode=mode)
         if i:
-            ms.append(t); st.append(ctx.stats()["ms_stream"])
+            s = ctx.stats()
+            ms.append(t); st.append(s["ms_stream"]); mid.append(s["ms_mid"])
     ctx.set_option("count_fragments", 1)
     ctx.render(M, sf, clear=True, mode=mode)
     frags = ctx.stats()["n_fragments"]
     ctx.set_option("count_fragments", 0)
-    gbps = B_ALG[args.mode] * n_per / (float(np.mean(st)) * 1e-3) / 1e9
-    return {"workload": f"same snapshot, h capped so footprints <= {cap_px:g} px", "ms_per_step": float(np.mean(ms)),
-            "value": n_per / (float(np.mean(ms)) * 1e-3), "unit": "particles/s", "fragments_per_particle": frags / n_per,
-            "stream_kernel_ms": float(np.mean(st)), "stream_kernel_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
+    b = B_ALG[args.mode] * n_per
+    gbps = b / (float(np.median(st)) * 1e-3) / 1e9
+    frame_gbps = b / (float(np.median(ms)) * 1e-3) / 1e9
+    return {"workload": f"same snapshot, h capped so footprints <= {cap_px:g} px", "ms_per_step": float(np.median(ms)),
+            "value": n_per / (float(np.median(ms)) * 1e-3), "unit": "particles/s", "fragments_per_particle": frags / n_per,
+            "stream_kernel_ms": float(np.median(st)), "mid_kernel_ms": float(np.median(mid)),
+            "stream_kernel_GBps": gbps, "frame_GBps": frame_gbps,
+            "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS, "frame_frac_of_hbm_peak": frame_gbps / HBM_PEAK_GBPS,
+            "frac_of_guide_measured_copy": gbps / HBM_MEASURED_COPY_GBPS, "frame_frac_of_guide_measured_copy": frame_gbps / HBM_MEASURED_COPY_GBPS,
             "frac_of_measured_read_peak": gbps / measured_peak}
 
 
-def config1_line(args, ctx, M, sf, n=10_000_000, frames=5):
-    """10M particles with the reference's synthetic quantity (stand-in for gas + temp), weighted render."""
+def config_line(ctx, n, mode_name, R, args, label, frames=10):
+    """One of BASELINE.json's other configurations on this GPU: camera A, reference h-law, generated on device, load-time
+    ordering; median of `frames` frames (splat only: tsp_render's own hipEvent time) after one warm-up."""
     from topsy_amd import _native
-    from topsy_amd.particle_buffers import ParticleBuffers
-    ctx.generate_synthetic(n, first=0, count=n, seed=1337, h_cap=0.0, with_quantity=True, with_rgb=False)
+    mode = _native.MODE_RGB if mode_name == "rgb" else _native.MODE_WEIGHTED
+    ctx.generate_synthetic(n, first=0, count=n, seed=1337, h_cap=0.0, with_quantity=mode_name == "weighted", with_rgb=mode_name == "rgb")
     if not args.no_reorder:
-        ctx.reorder_spatial(ParticleBuffers._num_strata(n), 1337)
-    ms = []
+        ctx.reorder_spatial(num_strata(n), 1337)
+    M, sf = camera(args.scale)
+    ms, per = [], {k: [] for k in KERNELS}
     for i in range(frames + 1):
-        t = ctx.render(M, sf, clear=True, mode=_native.MODE_WEIGHTED)
+        t = ctx.render(M, sf, clear=True, mode=mode)
         if i:
             ms.append(t)
-    st = ctx.stats()
-    return {"workload": f"{n:.3g} particles, density-weighted quantity, {args.resolution}^2 buffer, camera A, reference h-law",
-            "ms_per_step": float(np.mean(ms)), "value": n / (float(np.mean(ms)) * 1e-3), "unit": "particles/s",
-            "kernel_ms": {"stream": st["ms_stream"], "mid": st["ms_mid"], "huge": st["ms_huge"], "mega": st["ms_mega"]}}
+            st = ctx.stats()
+            for k in KERNELS:
+                per[k].append(st["ms_" + k])
+    ctx.set_option("count_fragments", 1)
+    ctx.render(M, sf, clear=True, mode=mode)
+    frags = ctx.stats()["n_fragments"]
+    ctx.set_option("count_fragments", 0)
+    med = float(np.median(ms))
+    return {"workload": f"{label}, {R}^2 buffer, camera A, reference h-law", "particles": n, "ms_per_step": med,
+            "value": n / (med * 1e-3), "unit": "particles/s", "frames_per_s": 1e3 / med, "fragments_per_particle": frags / n,
+            "kernel_ms": {k: float(np.median(v)) for k, v in per.items()}}
 
 
 def cpu_baseline(args, n_total, M, sf, R):

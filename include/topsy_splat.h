@@ -60,7 +60,11 @@ enum {
 };
 
 const char *tsp_last_error(void);
+/* ABI version.  100: first release.  101: tsp_stats grew by 16 bytes (ms_mega, n_mega appended) -- tsp_get_stats
+ * writes sizeof(tsp_stats) bytes, so a client compiled against the version-100 header must not be run against a
+ * version-101 library (check tsp_version() >= 101 and tsp_stats_size() == sizeof(tsp_stats) at start-up). */
 int tsp_version(void);
+int tsp_stats_size(void);
 
 /* Number of visible GPUs (hipGetDeviceCount); <0 on error. Does not create a HIP context. */
 int tsp_device_count(void);
@@ -208,7 +212,7 @@ int tsp_get_stats(tsp_context *ctx, tsp_stats *out);
 /* Enable fragment counting (adds atomics; off by default). */
 int tsp_set_option(tsp_context *ctx, const char *name, int64_t value);
 
-/* Streaming-read microbenchmark (float4 read-sum over `bytes` of device memory): returns GB/s.
+/* Streaming-read microbenchmark (float4 read-sum over `bytes` of device memory; best of a few launch shapes): returns GB/s.
  * The measured HBM peak BASELINE.md section 2 prices the roofline fraction against. */
 int tsp_measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, double *gbps_out);
 

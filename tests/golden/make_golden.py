@@ -11,6 +11,8 @@ Runs ONLY in the build container, where the read-only reference checkout is moun
   * params:   Colormap._update_parameter_buffer / _autorange_using_values outputs (:381-453)
   * driver:   RenderProgression(+WithCells) block sequences (reference src/topsy/progressive_render.py)
   * cells:    CellLayout.from_positions outputs (reference src/topsy/cell_layout.py:63-113)
+  * bands:    PynbodyDataInMemory.get_rgb_masses outputs on a stub snapshot of seeded SSP band magnitudes
+              (reference src/topsy/loader.py:112-121); `--bands-only` regenerates just this fixture
   * KATs:     the literal expected-output arrays held by the reference's own tests
               (tests/test_render_output.py, tests/test_colormap.py), extracted with `ast`.
 
@@ -86,7 +88,42 @@ class _RecordingDevice:
         return lambda *a, **k: _Stub("obj")
 
 
+def make_band_fixture():
+    """SSP band magnitudes -> rgb masses through the reference's PynbodyDataInMemory.get_rgb_masses
+    (reference src/topsy/loader.py:112-121) on a stub snapshot: seeded I/V/U magnitudes (float64, with NaNs, +-inf
+    and extreme values) and a seeded particle order.  Pins oracle_np.band_contraction and tsp_upload_band_magnitudes."""
+    _import_reference()
+    from topsy.loader import PynbodyDataInMemory
+
+    class _Snapshot(dict):
+        def __len__(self):
+            return len(self["I_mag"])
+
+    rs = np.random.RandomState(20260)
+    n = 4096
+    snap = _Snapshot()
+    for band, centre in (("I", 4.0), ("V", 5.0), ("U", 6.5)):
+        mag = centre + 3.0 * rs.normal(size=n)
+        mag[rs.choice(n, 40, replace=False)] = np.nan                 # stars without a magnitude in this band
+        mag[rs.choice(n, 8, replace=False)] = rs.choice([-60.0, 90.0, 110.0, 130.0], size=8)   # float32 overflow / underflow
+        mag[rs.choice(n, 4, replace=False)] = [np.inf, -np.inf, 0.0, -0.0]
+        snap[band + "_mag"] = mag
+    loader = PynbodyDataInMemory.__new__(PynbodyDataInMemory)
+    loader.snapshot = snap
+    loader._particle_order = rs.permutation(n)
+    with np.errstate(all="ignore"):
+        rgb = loader.get_rgb_masses()
+    assert rgb.dtype == np.float32 and rgb.shape == (n, 3)
+    np.savez_compressed(os.path.join(OUT, "band_magnitudes.npz"), I_mag=snap["I_mag"], V_mag=snap["V_mag"], U_mag=snap["U_mag"],
+                        particle_order=loader._particle_order.astype(np.int64), rgb=rgb)
+    print("wrote band_magnitudes.npz", rgb.shape, "non-finite:", int((~np.isfinite(rgb)).sum()), "zeros:", int((rgb == 0).sum()))
+
+
 def main():
+    if "--bands-only" in sys.argv:
+        make_band_fixture()
+        return
+    make_band_fixture()
     _import_reference()
     from topsy.loader import TestDataLoader
     from topsy import sph, progressive_render, cell_layout, config

@@ -59,10 +59,11 @@ def test_pipeline_equals_generic_and_oracle_1e6(native, mips):
     ctx.close()
 
 
-@pytest.mark.parametrize("n,hcap_px", [(20000000, 0.0), (100000000, 8.0)])
+@pytest.mark.parametrize("n,hcap_px", [(20000000, 0.0), (100000000, 8.0), (100000000, 0.0)])
 def test_mass_and_shard_additivity_at_scale(native, mips, n, hcap_px):
     """sum over pixels * pixel area == visible mass; image(shard A) + image(shard B) == image(all)
-    (index-range shards, BASELINE config 4's contract), up to float32 summation noise."""
+    (index-range shards, BASELINE config 4's contract), up to float32 summation noise.
+    (100000000, 0.0) is BASELINE config 3 at full size with the reference h-law (uncapped)."""
     R, scale = 1024, 200.0
     M, sf = camera(scale)
     hcap = hcap_px * scale / (2.0 * R)
@@ -260,3 +261,120 @@ def test_record_list_overflow_replay(native, mips, h_value, label):
     tol = 1e-5 * np.abs(g[..., 1]).max()
     assert np.abs(a[..., 1] - g[..., 1]).max() <= tol * 50      # channel 1 cancels (signed q): scale by sum|terms| ~ 50x max
     ctx.close()
+
+
+def test_config5_rgb_2048_full_size(native, mips):
+    """BASELINE config 5 at full size: 5e7 star particles, rgb, 2048^2 (reference test_rgb_sph_output,
+    tests/test_render_output.py:296-300, checks the mode at test size).  Pipeline (kernels S / M / gather) against the
+    generic atomic kernel: value channels within 1e-5, the fragment-count channel and the fragment total exact."""
+    n, R = 50_000_000, 2048
+    M, sf = camera(200.0)
+    ctx = native.Context(R, 4)
+    ctx.set_kernel_mips(mips)
+    ctx.generate_synthetic(n, 0, n, 1337, 0.0, with_quantity=False, with_rgb=True)
+    ctx.reorder_spatial(32, 1337)
+    ctx.set_option("count_fragments", 1)
+    ctx.render(M, sf, mode=native.MODE_RGB)
+    st = ctx.stats()
+    assert st["n_small"] + st["n_mid"] + st["n_huge"] + st["n_culled"] == n
+    assert st["n_huge"] > 0 and st["n_mid"] > 0 and st["n_small"] > 0
+    fa = st["n_fragments"]
+    a = ctx.read_image()
+    ctx.render(M, sf, mode=native.MODE_RGB, flags=native.PIPE_GENERIC)
+    assert ctx.stats()["n_fragments"] == fa
+    g = ctx.read_image()
+    assert np.array_equal(a[..., 3], g[..., 3]), "fragment-count channel must be exact"
+    for c in range(3):
+        assert rel_close(a[..., c].astype(np.float64), g[..., c].astype(np.float64), 1e-5), f"channel {c}"
+    ctx.close()
+
+
+def test_config2_weighted_1e7_full_size(native, mips):
+    """BASELINE config 2 at full size: 1e7 particles, density-weighted quantity, 1024^2: pipeline vs generic kernel."""
+    n, R = 10_000_000, 1024
+    M, sf = camera(200.0)
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.generate_synthetic(n, 0, n, 1337, 0.0, with_quantity=True)
+    ctx.reorder_spatial(32, 1337)
+    ctx.set_option("count_fragments", 1)
+    ctx.render(M, sf, mode=native.MODE_WEIGHTED)
+    st = ctx.stats()
+    assert st["n_small"] + st["n_mid"] + st["n_huge"] + st["n_culled"] == n and st["n_mega"] > 0
+    fa = st["n_fragments"]
+    a = ctx.read_image().astype(np.float64)
+    ctx.render(M, sf, mode=native.MODE_WEIGHTED, flags=native.PIPE_GENERIC)
+    assert ctx.stats()["n_fragments"] == fa
+    g = ctx.read_image().astype(np.float64)
+    assert rel_close(a[..., 0], g[..., 0], 1e-5)
+    # the weighted channel cancels (signed q): absolute tolerance scaled by the sum of |terms|, bounded by |q|max * density
+    qmax = 1e-4
+    assert (np.abs(a[..., 1] - g[..., 1]) <= 1e-5 * qmax * g[..., 0] + 1e-30).all()
+    ctx.close()
+
+
+def test_rgb_2048_matches_oracle_at_class_boundaries(native, mips):
+    """rgb at R = 2048 against the CPU oracle: a few thousand particles whose footprints sit on and around the class
+    boundaries 11.3 / 13.5 / 22.6 / 45.3 / 64 / 128 / 512 px (kernel S / M / gather kernels), plus a wide spread."""
+    from oracle import oracle_c
+    R, scale = 2048, 200.0
+    M, sf = camera(scale)
+    rs = np.random.RandomState(11)
+    n = 3000
+    pos = (rs.normal(size=(n, 3)) * np.array([60.0, 60.0, 30.0])).astype(np.float32)
+    bounds = np.array([11.3137, 13.5, 22.6274, 45.2548, 64.0, 128.0, 512.0, 700.0])
+    P = np.where(rs.uniform(size=n) < 0.6, rs.choice(bounds, size=n) * (1.0 + rs.choice([-1e-6, 0.0, 1e-6, 0.01, -0.01], size=n)),
+                 np.exp(rs.uniform(np.log(0.3), np.log(1500.0), size=n)))
+    h = (P * scale / (2.0 * R)).astype(np.float32)
+    rgb = rs.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32)
+    ctx = native.Context(R, 4)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, None)
+    ctx.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
+    ctx.set_option("count_fragments", 1)
+    ctx.render(M, sf, mode=native.MODE_RGB)
+    got = ctx.read_image()
+    nf = ctx.stats()["n_fragments"]
+    x, y, z = (np.ascontiguousarray(pos[:, k]) for k in range(3))
+    want, nfrag = oracle_c.splat(x, y, z, h, rgb[:, 0].copy(), rgb[:, 1].copy(), rgb[:, 2].copy(), mode=2, M=M, sf=float(sf), R=R, mips=mips)
+    assert nf == nfrag, "coverage decisions differ from the oracle"
+    assert np.array_equal(got[..., 3], want[..., 3]), "fragment-count channel must be exact"
+    assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("label,h_values", [("all-mega", (60.0,)), ("huge+mega", (20.0, 60.0))])
+def test_record_list_overflow_replay_with_mega_records(native, mips, label, h_values):
+    """The huge list holds H2's records from the front and H3's 'mega' records (P >= 512 px) from the back; an overflow
+    of the sum replays kernel S after growing the list.  n > 16 * 65536 so the first frame must overflow, grow and
+    replay with mega records taking part; weighted (NW = 1) and rgb (NW = 2 weights per record)."""
+    n, R = 1_100_000, 1024
+    rs = np.random.RandomState(8)
+    pos = (rs.normal(size=(n, 3)) * 60.0).astype(np.float32)
+    h = rs.choice(np.asarray(h_values, dtype=np.float32), size=n)          # P = 2 h R / scale = 204.8 px (H2) or 614.4 px (H3)
+    m = rs.uniform(0.5, 1.5, n).astype(np.float32)
+    rgb = rs.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32)
+    M, sf = camera(200.0)
+    for mode in (native.MODE_WEIGHTED, native.MODE_RGB):
+        c2 = native.Context(R, 4)                # fresh context per mode: its record lists start small again
+        c2.set_kernel_mips(mips)
+        c2.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+        c2.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
+        c2.render(M, sf, mode=mode)              # first frame: overflow -> grow -> replay
+        st = c2.stats()
+        a = c2.read_image().astype(np.float64)
+        assert st["n_huge"] > 16 * 65536 and st["n_small"] == 0 and st["n_mid"] == 0
+        if mode != native.MODE_RGB:              # rgb keeps every footprint >= 64 px on kernel H (no mega class)
+            assert st["n_mega"] > 0
+            assert (st["n_mega"] == st["n_huge"]) == (label == "all-mega")
+        assert st["n_huge"] + st["n_culled"] == n
+        c2.render(M, sf, mode=mode)              # second frame: the lists are large enough now
+        b = c2.read_image().astype(np.float64)
+        c2.render(M, sf, mode=mode, flags=native.PIPE_GENERIC)
+        g = c2.read_image().astype(np.float64)
+        nch = 3 if mode == native.MODE_RGB else 1
+        for c in range(nch):
+            assert rel_close(a[..., c], g[..., c], 1e-5) and rel_close(b[..., c], g[..., c], 1e-5), (label, mode, c)
+        if mode == native.MODE_RGB:
+            assert np.array_equal(a[..., 3], g[..., 3]) and np.array_equal(b[..., 3], g[..., 3])
+        c2.close()

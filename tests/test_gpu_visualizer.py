@@ -316,6 +316,12 @@ def test_periodic_sph_output(kats):               # reference test_periodic_sph_
     # and the product's own frame (render + tiling) agrees with it up to the summation order of the splat
     v.render_sph(DrawReason.EXPORT)
     npt.assert_allclose(v._sph._context.read_image(), tiled, rtol=1e-5, atol=1e-30)
+    # a depth query goes through the shared render target; a PRESENTATION_CHANGE afterwards must redraw the periodic
+    # frame (splat + tiling) instead of re-presenting the depth pass's image
+    v._sph.get_depth_image()
+    assert v._sph.render(DrawReason.PRESENTATION_CHANGE) is True
+    npt.assert_allclose(v._sph._context.read_image(), tiled, rtol=1e-5, atol=1e-30)
+    assert v._sph.render(DrawReason.PRESENTATION_CHANGE) is False      # now the frame is resident: nothing to do
     v.close()
 
 
@@ -433,3 +439,31 @@ def test_rgb_from_band_magnitudes_on_device():
         v.close()
     npt.assert_allclose(imgs[0][..., :3], imgs[1][..., :3], rtol=1e-5, atol=0)
     assert np.array_equal(imgs[0][..., 3], imgs[1][..., 3])
+
+
+def test_band_contraction_on_device_pinned_by_reference_fixture(golden):
+    """tsp_upload_band_magnitudes against the reference's own get_rgb_masses output (tests/golden/band_magnitudes.npz,
+    reference src/topsy/loader.py:112-121): one float32 ulp (device pow vs libm, both float64, one rounding); NaN -> 0,
+    inf and 0 reproduced exactly."""
+    from topsy_amd import _native, kernel_lut
+    g = golden["band_magnitudes.npz"]
+    order = g["particle_order"]
+    m = np.stack([g[b + "_mag"][order] for b in "IVU"])
+    w = np.diag([0.5, 1.0, 1.0])
+    want = g["rgb"]
+    n = len(order)
+    rs = np.random.RandomState(2)
+    pos = rs.normal(size=(n, 3)).astype(np.float32)
+    for reorder in (False, True):
+        ctx = _native.Context(64, 4)
+        ctx.set_kernel_mips(kernel_lut.kernel_mips())
+        ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], np.ones(n, np.float32), None)
+        perm = np.asarray(ctx.reorder_spatial(4, 9, want_permutation=True)) if reorder else np.arange(n)
+        ctx.upload_band_magnitudes(m, w)
+        d = ctx.download_particles(("r", "g", "b"))
+        got = np.stack([d["r"], d["g"], d["b"]], axis=1)
+        exp = want[perm]
+        special = ~np.isfinite(exp) | (exp == 0)
+        assert np.array_equal(got[special], exp[special])
+        npt.assert_allclose(got[~special], exp[~special], rtol=1.2e-7, atol=0)
+        ctx.close()

@@ -16,6 +16,7 @@ MODE_WEIGHTED, MODE_DEPTH, MODE_RGB = 0, 1, 2
 PIPE_DEFAULT, PIPE_GENERIC = 0, 1
 SAMPLE_BILINEAR_MIP0, SAMPLE_BILINEAR_MIP = 0x10, 0x20      # diagnostic sampling rules (generic kernel)
 UNIQUE_ID_BYTES = 128
+ABI_VERSION = 101            # include/topsy_splat.h: tsp_version()
 
 
 class BackendUnavailable(RuntimeError):
@@ -45,6 +46,7 @@ _ctx = ctypes.c_void_p
 SIGNATURES = {
     "tsp_last_error": (ctypes.c_char_p, []),
     "tsp_version": (ctypes.c_int, []),
+    "tsp_stats_size": (ctypes.c_int, []),
     "tsp_device_count": (ctypes.c_int, []),
     "tsp_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_ctx)]),
     "tsp_destroy": (None, [_ctx]),
@@ -110,6 +112,9 @@ def load_library():
             raise BackendUnavailable(f"{LIB_PATH} does not export {name}") from e
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.tsp_version() < ABI_VERSION or lib.tsp_stats_size() != ctypes.sizeof(Stats):
+        raise BackendUnavailable(f"{LIB_PATH} has ABI version {lib.tsp_version()} / tsp_stats of {lib.tsp_stats_size()} bytes; "
+                                 f"this binding needs version >= {ABI_VERSION} and {ctypes.sizeof(Stats)} bytes: rebuild the library")
     _lib = lib
     return lib
 

@@ -95,7 +95,8 @@ using namespace tsp;
 extern "C" {
 
 const char *tsp_last_error(void) { return g_err; }
-int tsp_version(void) { return 100; }
+int tsp_version(void) { return 101; }     // 101: tsp_stats gained ms_mega, n_mega (16 bytes)
+int tsp_stats_size(void) { return (int)sizeof(tsp_stats); }
 
 int tsp_device_count(void) {
     int n = 0;

@@ -730,7 +730,8 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     if (!(ctx->kernel_attr_done & (1u << MODE))) {
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WinSize<C>::value * WinSize<C>::value * sizeof(double) + 1280)));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WinSize<1>::value * WinSize<1>::value * sizeof(double) + 1280)));
-        const int lds_m = (int)((size_t)C * 32 * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float));
+        // + the largest debug_extra_lds (tsp_set_option): the attribute is an upper limit and does not affect the occupancy
+        const int lds_m = (int)((size_t)C * 32 * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float)) + 65536;
         TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, WCM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, WCM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));

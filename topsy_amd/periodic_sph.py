@@ -31,9 +31,11 @@ class PeriodicSPH(sph.SPH):
         self.num_repetitions = 2
 
     def render(self, draw_reason=DrawReason.CHANGE):
-        if draw_reason == DrawReason.PRESENTATION_CHANGE:
-            return
-        super().render(draw_reason)
+        # the base class decides whether anything is drawn: a PRESENTATION_CHANGE re-presents the resident tiled frame,
+        # unless another renderer (e.g. the depth pass) has used the shared target since -- then the frame is redrawn
+        if not super().render(draw_reason):
+            return False
         panel_scale = self._visualizer.periodicity_scale / self._visualizer.scale
         offsets, weights = instance_offsets_and_weights(self.rotation_matrix, panel_scale, self.num_repetitions)
         self._context.tile_periodic(offsets, weights)
+        return True

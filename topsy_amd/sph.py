@@ -95,11 +95,13 @@ class SPH:
         return self.has_rendered and getattr(self._visualizer.particle_buffers, "last_renderer", None) is self
 
     def render(self, draw_reason=DrawReason.CHANGE):
+        """One frame of render blocks.  Returns True when the render target was (re)drawn, False when the resident
+        image is simply presented again (PRESENTATION_CHANGE with this renderer's frame still in the target)."""
         if draw_reason in (DrawReason.REFINE, DrawReason.PRESENTATION_CHANGE) and not self._target_is_mine():
             # nothing of ours to refine / re-present: start the frame again
             draw_reason = DrawReason.CHANGE
         if draw_reason == DrawReason.PRESENTATION_CHANGE:
-            return
+            return False
         rp = self._render_progression
         if draw_reason != DrawReason.REFINE:
             rp.select_sphere(-np.asarray(self.position_offset), self.scale * 1.2)
@@ -121,6 +123,7 @@ class SPH:
         self.last_render_fps = 1.0 / mean if mean > 0 else float("inf")
         self.has_rendered = True
         self._visualizer.particle_buffers.last_renderer = self
+        return True
 
     def needs_refine(self):
         return self._render_progression.needs_refine()
