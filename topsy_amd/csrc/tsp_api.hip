@@ -642,8 +642,8 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         ctx->count_fragments = value != 0;
         return TSP_OK;
     }
-    if (!strcmp(name, "p_small_milli")) {     // class boundary small/mid in 1/1000 px (<= 22627: kernel S holds mips 2 and 3)
-        TSP_REQUIRE(value >= 0 && value <= 22627, TSP_EINVAL, "p_small out of range");
+    if (!strcmp(name, "p_small_milli")) {     // class boundary small/mid in 1/1000 px (<= 16000: kernel S holds mips 2 and 3 and packs <= 16 texel columns)
+        TSP_REQUIRE(value >= 0 && value <= 16000, TSP_EINVAL, "p_small out of range (kernel S packs <= 16 texel columns per footprint)");
         ctx->p_small = (float)value * 1e-3f;
         return TSP_OK;
     }

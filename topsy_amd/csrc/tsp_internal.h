@@ -100,6 +100,7 @@ struct tsp_context {
     int64_t sort_capacity = 0, sorted_count = 0;
     tsp_stats stats = {};
     std::vector<int64_t> strata_offsets;   // first index of every stratum of the last reorder_spatial, then n
+    int mid_attr_extra[3] = {-1, -1, -1};   // per render mode: the debug_extra_lds value kernel M's dynamic-LDS limit was last set for
     uint32_t kernel_attr_done = 0;   // bit per kernel family whose dynamic-LDS limit was raised on this context's device
     bool count_fragments = false;
     // pipeline tuning (tsp_set_option)

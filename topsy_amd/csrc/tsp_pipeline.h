@@ -38,7 +38,10 @@ __device__ __forceinline__ void latomic_add(double *addr, float v) {
     __hip_atomic_fetch_add(addr, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-constexpr int HDEAL = 16;            // records per dealing run of the tile-gather kernels (1: 13.6 ms, 4: 10.67, 16: 10.49, 64: 10.71 for H2)
+#ifndef TSP_HDEAL
+#define TSP_HDEAL 16
+#endif
+constexpr int HDEAL = TSP_HDEAL;            // records per dealing run of the tile-gather kernels (1: 13.6 ms, 4: 10.67, 16: 10.49, 64: 10.71 for H2)
 
 struct TileArgs {
     const float4 *geom; const float *w;

@@ -59,6 +59,21 @@ __device__ __forceinline__ float wave_max(float v) {
                                  [](int a, int b) { return __float_as_int(fmaxf(__int_as_float(a), __int_as_float(b))); });
     return __int_as_float(__builtin_amdgcn_readlane(r, 63));
 }
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_min_u16(unsigned a, unsigned b) {       // both 16-bit halves at once (v_pk_min_u16)
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ unsigned wave_pk_min_u16(unsigned v) {
+    const int r = wave_scan_bits((int)v, -1, [](int a, int b) { return (int)pk_min_u16((unsigned)a, (unsigned)b); });
+    return (unsigned)__builtin_amdgcn_readlane(r, 63);
+}
+__device__ __forceinline__ unsigned wave_pk_max_u16(unsigned v) {
+    const int r = wave_scan_bits((int)v, 0, [](int a, int b) { return (int)pk_max_u16((unsigned)a, (unsigned)b); });
+    return (unsigned)__builtin_amdgcn_readlane(r, 63);
+}
 __device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/) {
     return wave_scan_bits(v, 0, [](int a, int b) { return a + b; });
 }
@@ -92,8 +107,8 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
     double *win = smem_d;                                            // [WC][WIN*WIN]
     float *T23 = reinterpret_cast<float *>(win + WC * WIN * WIN);    // mip levels 2 (16x16) and 3 (8x8): 320 floats
-    __shared__ float s_red[4][4], s_mbb[4][4];
-    __shared__ int s_cnt[4][2];
+    __shared__ unsigned s_red[4][2], s_mbb[4][2];
+    __shared__ int s_cnt[4];
     __shared__ long long s_base[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -172,34 +187,37 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
     if (c_begin < c_end) { locate(c_begin, first, cnt); load_chunk(first, cnt); }
     for (int c = c_begin; c < c_end; ++c) {
 
-        // ---- phase 1: coalesced loads, projection, classification ------------------------------
-        float pcx[KPT], pcy[KPT], PP[KPT], w0[KPT], w1[KPT], w2[KPT];
+        // ---- phase 1: projection, exact covered pixel ranges, classification ------------------------------------
+        // Bounding boxes are kept as PACKED 16-bit pixel pairs (x | y << 16; the image has <= 16384 pixels per side):
+        // one v_pk_min_u16 / v_pk_max_u16 per reduction step does both axes.
+        float pcx[KPT], pcy[KPT], PP[KPT], invP[KPT], w0[KPT], w1[KPT], w2[KPT];
         int cls[KPT];
-        int xr[KPT], yr[KPT];          // small footprints: first covered pixel | (number of covered pixels << 16)
-        float bx0 = 3.0e38f, by0 = 3.0e38f, bx1 = -3.0e38f, by1 = -3.0e38f;      // small footprints
-        float mx0 = 3.0e38f, my0 = 3.0e38f, mx1 = -3.0e38f, my1 = -3.0e38f;      // mid footprints
-        int my_mid = 0, my_huge = 0;
+        unsigned xr[KPT], yr[KPT];     // first covered pixel | (number of covered pixels << 16), clipped to the image
+        unsigned s_lo = 0xffffffffu, s_hi = 0u;      // covered-pixel bounding box of the small footprints: (ilo | jlo << 16), (ihi | jhi << 16)
+        unsigned m_lo = 0xffffffffu, m_hi = 0u;      // the same for the mid footprints
+        int my_counts = 0;                           // mid records | huge records << 16 of this lane
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const int li = k * 256 + tid;
             cls[k] = CLS_NONE;
-            pcx[k] = pcy[k] = PP[k] = w0[k] = w1[k] = w2[k] = 0.0f;
-            xr[k] = yr[k] = 0;
+            pcx[k] = pcy[k] = PP[k] = invP[k] = w0[k] = w1[k] = w2[k] = 0.0f;
+            xr[k] = yr[k] = 0u;
             if (li < cnt) {
                 const float h = L[k][3];
                 const Proj pr = project(cam, L[k][0], L[k][1], L[k][2], h);
                 bool vis = false;
+                int ilo = 0, ihi = 0, jlo = 0, jhi = 0;
                 if (pr.keep) {
                     // any pixel centre covered?  (exact test via the canonical interval)
-                    int ilo, ihi, jlo, jhi;
                     cover_range(pr.pcx, pr.half, R, ilo, ihi);
                     cover_range(pr.pcy, pr.half, R, jlo, jhi);
                     vis = (ilo <= ihi) && (jlo <= jhi);
-                    // a small footprint covers <= 23 pixels per axis and R <= 16384: both fit 16 bits
-                    xr[k] = ilo | (min(ihi - ilo + 1, 0xffff) << 16);
-                    yr[k] = jlo | (min(jhi - jlo + 1, 0xffff) << 16);
                 }
                 if (vis) {
+                    // a small footprint covers <= 16 pixels per axis and R <= 16384: both fit 16 bits
+                    xr[k] = (unsigned)ilo | ((unsigned)min(ihi - ilo + 1, 0xffff) << 16);
+                    yr[k] = (unsigned)jlo | ((unsigned)min(jhi - jlo + 1, 0xffff) << 16);
+                    const unsigned lo = (unsigned)ilo | ((unsigned)jlo << 16), hi = (unsigned)ihi | ((unsigned)jhi << 16);
                     const float hh = h * h;
                     if (MODE == TSP_MODE_RGB) {
                         w0[k] = L[k][4] / hh; w1[k] = L[k][5] / hh; w2[k] = L[k][6] / hh;
@@ -207,17 +225,15 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
                         w0[k] = L[k][4] / hh;
                         w1[k] = (MODE == TSP_MODE_DEPTH) ? pr.cz : L[k][5];
                     }
-                    pcx[k] = pr.pcx; pcy[k] = pr.pcy; PP[k] = pr.P;
+                    pcx[k] = pr.pcx; pcy[k] = pr.pcy; PP[k] = pr.P; invP[k] = pr.invP;
                     if (pr.P < a.p_small) {
                         cls[k] = CLS_SMALL;
-                        bx0 = fminf(bx0, pr.pcx - pr.half); bx1 = fmaxf(bx1, pr.pcx + pr.half);
-                        by0 = fminf(by0, pr.pcy - pr.half); by1 = fmaxf(by1, pr.pcy + pr.half);
+                        s_lo = pk_min_u16(s_lo, lo); s_hi = pk_max_u16(s_hi, hi);
                     } else if (pr.P < P_BILINEAR) {
-                        cls[k] = CLS_MID; ++my_mid;
-                        mx0 = fminf(mx0, pr.pcx - pr.half); mx1 = fmaxf(mx1, pr.pcx + pr.half);
-                        my0 = fminf(my0, pr.pcy - pr.half); my1 = fmaxf(my1, pr.pcy + pr.half);
+                        cls[k] = CLS_MID; my_counts += 1;
+                        m_lo = pk_min_u16(m_lo, lo); m_hi = pk_max_u16(m_hi, hi);
                     } else if (pr.P < a.p_mega) {
-                        cls[k] = CLS_HUGE; ++my_huge;
+                        cls[k] = CLS_HUGE; my_counts += 1 << 16;
                     } else {
                         cls[k] = CLS_MEGA;          // rare (~1e-3 of the particles): one atomic each, below
                     }
@@ -233,16 +249,13 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
         // ---- phase 2: the chunk's small-footprint bounding box places the LDS window (uniform) ------
         // (each exchange has its own LDS scratch, so one barrier per exchange suffices: the barriers of
         // the following exchanges order its readers before the next chunk's writers)
-        bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1);
-        if (lane == 0) { s_red[wv][0] = bx0; s_red[wv][1] = by0; s_red[wv][2] = bx1; s_red[wv][3] = by1; }
+        s_lo = wave_pk_min_u16(s_lo); s_hi = wave_pk_max_u16(s_hi);
+        if (lane == 0) { s_red[wv][0] = s_lo; s_red[wv][1] = s_hi; }
         __syncthreads();
-        bx0 = fminf(fminf(s_red[0][0], s_red[1][0]), fminf(s_red[2][0], s_red[3][0]));
-        by0 = fminf(fminf(s_red[0][1], s_red[1][1]), fminf(s_red[2][1], s_red[3][1]));
-        bx1 = fmaxf(fmaxf(s_red[0][2], s_red[1][2]), fmaxf(s_red[2][2], s_red[3][2]));
-        by1 = fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3]));
-        if (bx1 >= bx0) {
-            const int ix0 = max((int)__builtin_floorf(bx0), 0), ix1 = min((int)__builtin_floorf(bx1), R - 1);
-            const int iy0 = max((int)__builtin_floorf(by0), 0), iy1 = min((int)__builtin_floorf(by1), R - 1);
+        s_lo = pk_min_u16(pk_min_u16(s_red[0][0], s_red[1][0]), pk_min_u16(s_red[2][0], s_red[3][0]));
+        s_hi = pk_max_u16(pk_max_u16(s_red[0][1], s_red[1][1]), pk_max_u16(s_red[2][1], s_red[3][1]));
+        if ((s_hi & 0xffffu) >= (s_lo & 0xffffu)) {          // the chunk has small footprints
+            const int ix0 = (int)(s_lo & 0xffffu), iy0 = (int)(s_lo >> 16), ix1 = (int)(s_hi & 0xffffu), iy1 = (int)(s_hi >> 16);
             const bool inside = ix0 >= wox && ix1 < wox + WIN && iy0 >= woy && iy1 < woy + WIN;
             if (!inside) {
                 flush();
@@ -251,7 +264,6 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
                 woy = (iy0 + iy1 + 1 - WIN) / 2;
                 wox = max(0, min(wox, R - WIN));
                 woy = max(0, min(woy, R - WIN));
-                wox = max(wox, 0); woy = max(woy, 0);
             }
             // dirty rectangle grows by this chunk's bbox (clipped to the window)
             dx0 = min(dx0, max(ix0 - wox, 0)); dx1 = max(dx1, min(ix1 - wox, WIN - 1));
@@ -263,74 +275,119 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             if (cls[k] != CLS_SMALL) continue;
-            const int ilo = xr[k] & 0xffff, ihi = ilo + (xr[k] >> 16) - 1;
-            const int jlo = yr[k] & 0xffff, jhi = jlo + (yr[k] >> 16) - 1;
+            const int ilo = (int)(xr[k] & 0xffffu), ihi = ilo + (int)(xr[k] >> 16) - 1;
+            const int jlo = (int)(yr[k] & 0xffffu), jhi = jlo + (int)(yr[k] >> 16) - 1;
             if (ilo < wox || ihi >= wox + WIN || jlo < woy || jhi >= woy + WIN) {
-                cls[k] = CLS_MID; ++my_mid;
-                const float half = 0.5f * PP[k];
-                mx0 = fminf(mx0, pcx[k] - half); mx1 = fmaxf(mx1, pcx[k] + half);
-                my0 = fminf(my0, pcy[k] - half); my1 = fmaxf(my1, pcy[k] + half);
+                cls[k] = CLS_MID; my_counts += 1;
+                m_lo = pk_min_u16(m_lo, (unsigned)ilo | ((unsigned)jlo << 16));
+                m_hi = pk_max_u16(m_hi, (unsigned)ihi | ((unsigned)jhi << 16));
             }
         }
         // record counts + offsets and the bounding box of the chunk's MID footprints
-        const int mid_incl = wave_incl_scan(my_mid, lane), huge_incl = wave_incl_scan(my_huge, lane);
-        const unsigned long long any_mid = __ballot(my_mid > 0);
-        if (any_mid) { mx0 = wave_min(mx0); my0 = wave_min(my0); mx1 = wave_max(mx1); my1 = wave_max(my1); }
-        if (lane == 63) { s_cnt[wv][0] = mid_incl; s_cnt[wv][1] = huge_incl; }
-        if (lane == 0) { s_mbb[wv][0] = mx0; s_mbb[wv][1] = my0; s_mbb[wv][2] = mx1; s_mbb[wv][3] = my1; }
+        const int counts_incl = wave_incl_scan(my_counts, lane);       // both counters at once: <= 128 each per wave
+        const unsigned long long any_mid = __ballot((my_counts & 0xffff) != 0);
+        if (any_mid) { m_lo = wave_pk_min_u16(m_lo); m_hi = wave_pk_max_u16(m_hi); }
+        if (lane == 63) s_cnt[wv] = counts_incl;
+        if (lane == 0) { s_mbb[wv][0] = m_lo; s_mbb[wv][1] = m_hi; }
         __syncthreads();
-        int mid_before = 0, huge_before = 0, mid_total = 0, huge_total = 0;
+        int counts_before = 0, counts_total = 0;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            if (w < wv) { mid_before += s_cnt[w][0]; huge_before += s_cnt[w][1]; }
-            mid_total += s_cnt[w][0]; huge_total += s_cnt[w][1];
+            if (w < wv) counts_before += s_cnt[w];
+            counts_total += s_cnt[w];
         }
+        const int mid_total = counts_total & 0xffff, huge_total = counts_total >> 16;
         // reserve contiguous runs in the record lists (one atomic per chunk and list)
         if (tid == 0) {
             s_base[0] = mid_total ? (long long)atomicAdd(&a.cnt->n_mid, (unsigned long long)mid_total) : 0;
             s_base[1] = huge_total ? (long long)atomicAdd(&a.cnt->n_huge, (unsigned long long)huge_total) : 0;
             a.seg_count[c] = mid_total;
             a.seg_offset[c] = s_base[0];
-            if (mid_total)
-                a.seg_bbox[c] = make_float4(fminf(fminf(s_mbb[0][0], s_mbb[1][0]), fminf(s_mbb[2][0], s_mbb[3][0])),
-                                            fminf(fminf(s_mbb[0][1], s_mbb[1][1]), fminf(s_mbb[2][1], s_mbb[3][1])),
-                                            fmaxf(fmaxf(s_mbb[0][2], s_mbb[1][2]), fmaxf(s_mbb[2][2], s_mbb[3][2])),
-                                            fmaxf(fmaxf(s_mbb[0][3], s_mbb[1][3]), fmaxf(s_mbb[2][3], s_mbb[3][3])));
+            if (mid_total) {
+                // covered-pixel bounds [x0, x1] x [y0, y1] stored as (x0, y0, x1 + 1, y1 + 1): kernel M's tile test
+                // bb.x < tile_x1 && bb.z > tile_x0 is then exact for integer tile edges
+                const unsigned lo = pk_min_u16(pk_min_u16(s_mbb[0][0], s_mbb[1][0]), pk_min_u16(s_mbb[2][0], s_mbb[3][0]));
+                const unsigned hi = pk_max_u16(pk_max_u16(s_mbb[0][1], s_mbb[1][1]), pk_max_u16(s_mbb[2][1], s_mbb[3][1]));
+                a.seg_bbox[c] = make_float4((float)(lo & 0xffffu), (float)(lo >> 16), (float)((hi & 0xffffu) + 1u), (float)((hi >> 16) + 1u));
+            }
         }
         __syncthreads();
         const long long mid_base = s_base[0], huge_base = s_base[1];
+        const int my_mid = my_counts & 0xffff, my_huge = my_counts >> 16;
+        const int mid_before = counts_before & 0xffff, huge_before = counts_before >> 16;
+        const int mid_incl = counts_incl & 0xffff, huge_incl = counts_incl >> 16;
 
         // ---- phase 4: rasterise small footprints (one lane per particle, mips 3 / 2 nearest) -----
+        // Nearest sampling is separable: texel column tx(i) and row ty(j).  The column indices of the whole footprint are
+        // computed once (4 bits each, <= 16 columns), then per pixel row: one ty, the row's LUT values fetched in a batch
+        // (LDS latency paid once per row, not per pixel), and per pixel a multiply, a conversion and the ds_add_f64.
+        // Loop bounds are wave-uniform (maximum over the lanes), lanes are predicated.
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            if (cls[k] != CLS_SMALL || !a.emit_small) continue;
-            const float half = 0.5f * PP[k], invP = 1.0f / PP[k];
-            const int ilo = xr[k] & 0xffff, ihi = ilo + (xr[k] >> 16) - 1;
-            const int jlo = yr[k] & 0xffff, jhi = jlo + (yr[k] >> 16) - 1;
-            // mip 3 up to 11.3 px, mip 2 up to 22.6 px (p_small may reach that far)
-            const int n = PP[k] > P_L2 ? 16 : 8, toff = PP[k] > P_L2 ? 0 : 256;
-            for (int j = jlo; j <= jhi; ++j) {
-                const float dy = ((float)j + 0.5f) - pcy[k];
-                const int ty = toff + nearest_index((dy + half) * invP, n) * n;
-                double *drow = win + (j - woy) * WIN - wox;
-                for (int i = ilo; i <= ihi; ++i) {
-                    const float dx = ((float)i + 0.5f) - pcx[k];
-                    const int tx = nearest_index((dx + half) * invP, n);
-                    const float kv = T23[ty + tx];
-                    double *d = drow + i;
-                    if (MODE == TSP_MODE_RGB) {
-                        latomic_add(d, kv * w0[k]); latomic_add(d + WIN * WIN, kv * w1[k]);
-                        latomic_add(d + 2 * WIN * WIN, kv * w2[k]); latomic_add(d + 3 * WIN * WIN, 1.0f);
-                    } else {
-                        if (kv == 0.0f) continue;      // corner texels are exactly 0: adding +-0 changes nothing
-                        const float val = kv * w0[k];
-                        latomic_add(d, val);
-                        if (WC > 1) latomic_add(d + WIN * WIN, val * w1[k]);
+            const bool act = (cls[k] == CLS_SMALL) && a.emit_small;
+            if (__ballot(act) == 0ull) continue;
+            const int nx = act ? (int)(xr[k] >> 16) : 0, ny = act ? (int)(yr[k] >> 16) : 0;
+            const int ilo = (int)(xr[k] & 0xffffu), jlo = (int)(yr[k] & 0xffffu);
+            const float half = 0.5f * PP[k], ip = invP[k];
+            // mip 3 (8 x 8) up to 11.3 px, mip 2 (16 x 16) above (p_small may reach 15 px)
+            const bool lvl2 = PP[k] > P_L2;
+            const float nf = lvl2 ? 16.0f : 8.0f;
+            const int nm1 = lvl2 ? 15 : 7;
+            unsigned pk_lo = 0u, pk_hi = 0u;          // texel column of footprint column c: 4 bits each
+            const float x0f = (float)ilo + 0.5f;      // centre of the first covered column ((float)(ilo + c) + 0.5f == x0f + c exactly)
+            int maxnx = 0;
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci) {
+                if (__ballot(ci < nx) == 0ull) break;
+                maxnx = ci + 1;
+                const float dx = (x0f + (float)ci) - pcx[k];
+                const int tx = clampi((int)__builtin_floorf(((dx + half) * ip) * nf), 0, nm1);
+                if (ci < 8) pk_lo |= (unsigned)tx << (4 * (ci & 7)); else pk_hi |= (unsigned)tx << (4 * (ci & 7));
+            }
+            const float y0f = (float)jlo + 0.5f;
+            const float *lut = T23 + (lvl2 ? 0 : 256);
+            const int lstride = lvl2 ? 16 : 8;
+            double *wbase = win + (jlo - woy) * WIN + (ilo - wox);
+            for (int r = 0; r < 16; ++r) {
+                const bool rowact = r < ny;
+                if (__ballot(rowact) == 0ull) break;
+                const float dy = (y0f + (float)r) - pcy[k];
+                const int ty = clampi((int)__builtin_floorf(((dy + half) * ip) * nf), 0, nm1);
+                const float *lrow = lut + ty * lstride;
+                const int nxr = rowact ? nx : 0;      // columns of this lane in this row
+                double *wrow = wbase + r * WIN;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    if (8 * g >= maxnx) break;
+                    const unsigned pk = g ? pk_hi : pk_lo;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[j] = 0.0f;
+                        if (8 * g + j < maxnx) v[j] = lrow[(pk >> (4 * j)) & 15u];      // (fields beyond nx are 0: a valid address)
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int ci = 8 * g + j;
+                        if (ci >= maxnx) break;
+                        if (ci < nxr) {
+                            double *d = wrow + ci;
+                            if (MODE == TSP_MODE_RGB) {
+                                latomic_add(d, v[j] * w0[k]); latomic_add(d + WIN * WIN, v[j] * w1[k]);
+                                latomic_add(d + 2 * WIN * WIN, v[j] * w2[k]); latomic_add(d + 3 * WIN * WIN, 1.0f);
+                            } else if (v[j] != 0.0f) {      // corner texels are exactly 0: adding +-0 changes nothing
+                                const float val = v[j] * w0[k];
+                                latomic_add(d, val);
+                                if (WC > 1) latomic_add(d + WIN * WIN, val * w1[k]);
+                            }
+                        }
                     }
                 }
             }
-            ++n_small;
-            if (a.count_frag) n_frag += (unsigned long long)((ihi - ilo + 1) * (jhi - jlo + 1));
+            if (act) {
+                ++n_small;
+                if (a.count_frag) n_frag += (unsigned long long)(nx * ny);
+            }
         }
 
         // ---- phase 5: append the deferred footprints -----------------------------------------------
@@ -730,13 +787,24 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     if (!(ctx->kernel_attr_done & (1u << MODE))) {
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WinSize<C>::value * WinSize<C>::value * sizeof(double) + 1280)));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WinSize<1>::value * WinSize<1>::value * sizeof(double) + 1280)));
-        // + the largest debug_extra_lds (tsp_set_option): the attribute is an upper limit and does not affect the occupancy
-        const int lds_m = (int)((size_t)C * 32 * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float)) + 65536;
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, WCM, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, WCM, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_mid_kernel<MODE, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m));
         ctx->kernel_attr_done |= 1u << MODE;
+        ctx->mid_attr_extra[MODE] = -1;
+    }
+    if (ctx->mid_attr_extra[MODE] != ctx->debug_extra_lds) {
+        // the dynamic-LDS limit of kernel M follows the debug_extra_lds option (a measurement aid that lowers its occupancy)
+        const int lds_m = (int)((size_t)C * 32 * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float)) + ctx->debug_extra_lds;
+        const void *fns[4] = {(const void *)splat_mid_kernel<MODE, WCM, false>, (const void *)splat_mid_kernel<MODE, 1, false>,
+                              (const void *)splat_mid_kernel<MODE, WCM, true>, (const void *)splat_mid_kernel<MODE, 1, true>};
+        for (const void *fn : fns) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("kernel M cannot take %d bytes of dynamic LDS (%s)%s", lds_m, hipGetErrorString(e),
+                          ctx->debug_extra_lds > 0 ? ": lower the debug_extra_lds option" : "");
+                return ctx->debug_extra_lds > 0 ? TSP_EINVAL : TSP_EHIP;
+            }
+        }
+        ctx->mid_attr_extra[MODE] = ctx->debug_extra_lds;
     }
 
     Counters hc, carry;
