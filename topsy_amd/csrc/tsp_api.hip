@@ -647,6 +647,10 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         ctx->p_small = (float)value * 1e-3f;
         return TSP_OK;
     }
+    if (!strcmp(name, "debug_no_raster")) {
+        ctx->debug_no_raster = value != 0;
+        return TSP_OK;
+    }
     if (!strcmp(name, "debug_extra_lds")) {
         TSP_REQUIRE(value >= 0 && value <= 65536, TSP_EINVAL, "%s out of range", name);
         ctx->debug_extra_lds = (int)value;

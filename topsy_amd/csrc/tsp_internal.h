@@ -110,6 +110,7 @@ struct tsp_context {
     int mid_split = 128, huge_split = 0, mega_split = 0;  // workgroups per image tile (0 = auto)
     int stream_blocks_per_cu = 100;  // kernel S grid bound: ~10 chunks per workgroup at 1e8 particles balances dense and sparse chunks
     bool overlap_mid_huge = false;    // option: kernels M and H on two streams (measured: no gain at 1.25e8, +6 % at 1e7)
+    bool debug_no_raster = false;    // measurement aid: kernel S classifies and emits records but rasterises nothing (the image is then incomplete)
     int debug_extra_lds = 0;         // measurement aid: extra dynamic LDS per workgroup of kernel M (lowers its occupancy)
     int cu_count = 256;
     // RCCL

@@ -78,6 +78,12 @@ __device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/) {
     return wave_scan_bits(v, 0, [](int a, int b) { return a + b; });
 }
 
+// Sum of v over the lanes of the wave (every lane must take part; inactive contributions are passed as 0)
+__device__ __forceinline__ float wave_sum(float v) {
+    const int r = wave_scan_bits(__float_as_int(v), 0, [](int a, int b) { return __float_as_int(__int_as_float(a) + __int_as_float(b)); });
+    return __int_as_float(__builtin_amdgcn_readlane(r, 63));
+}
+
 struct StreamArgs {
     Particles p;
     const int64_t *ranges;     // starts[n] | lens[n] | chunk_prefix[n+1]
@@ -348,6 +354,40 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
             const float *lut = T23 + (lvl2 ? 0 : 256);
             const int lstride = lvl2 ? 16 : 8;
             double *wbase = win + (jlo - woy) * WIN + (ilo - wox);
+            if (MODE != TSP_MODE_RGB && WC == 1 && maxnx == 1) {
+                // Every footprint of this wave is one pixel COLUMN wide: the dense core of the snapshot, where thousands of
+                // sub-pixel particles share a pixel and neighbouring lanes (load-time Morton order) mostly hit the SAME
+                // pixel -- a same-address ds_add_f64 costs ~11 clk per extra lane (most of such a wave's lanes draw nothing:
+                // a footprint narrower than a pixel rarely covers a pixel centre).  When they are single pixels, the lanes
+                // that hit one pixel are summed across the wave first (DPP tree) and one lane issues the one atomic.
+                if (__ballot(act && ny != 1) == 0ull) {
+                    const float dy = y0f - pcy[k];
+                    const int ty = clampi((int)__builtin_floorf(((dy + half) * ip) * nf), 0, nm1);
+                    const float kv = act ? lut[ty * lstride + (int)(pk_lo & 15u)] : 0.0f;
+                    const float val = kv * w0[k];
+                    const int key = (int)(wbase - win);
+                    unsigned long long todo = __ballot(act && val != 0.0f);
+                    // up to four distinct pixels are summed across the wave (float32 tree sums of <= 64 terms), one atomic
+                    // each; whatever is left after that (a sparse wave) adds lane by lane as before
+                    for (int round = 0; round < 4 && todo != 0ull; ++round) {
+                        const int src = __ffsll((long long)todo) - 1;
+                        const int k0 = __builtin_amdgcn_readlane(key, src);
+                        const bool match = act && val != 0.0f && key == k0;
+                        const unsigned long long mm = __ballot(match);
+                        todo &= ~mm;
+                        if (__popcll(mm) == 1) {
+                            if (lane == src) latomic_add(win + key, val);
+                        } else {
+                            const float sum = wave_sum(match ? val : 0.0f);
+                            if (lane == src) latomic_add(win + key, sum);
+                        }
+                    }
+                    if ((todo >> lane) & 1ull) latomic_add(win + key, val);
+                    n_small += act ? 1 : 0;
+                    if (a.count_frag) n_frag += act ? 1ull : 0ull;
+                    continue;
+                }
+            }
             for (int r = 0; r < 16; ++r) {
                 const bool rowact = r < ny;
                 if (__ballot(rowact) == 0ull) break;
@@ -822,7 +862,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         sa.huge_geom = (float4 *)ws.huge_geom; sa.huge_w = (float *)ws.huge_w; sa.huge_capacity = ws.huge_capacity;
         sa.seg_count = ws.seg_count; sa.seg_offset = ws.seg_offset; sa.seg_bbox = ws.seg_bbox;
         sa.cnt = ctx->counters; sa.p_small = ctx->p_small; sa.p_mega = (ctx->huge_variant != 0 && MODE != TSP_MODE_RGB && ctx->p_mega > 0.0f) ? ctx->p_mega : __builtin_inff(); sa.count_frag = ctx->count_fragments ? 1 : 0;
-        sa.emit_small = attempt == 0 ? 1 : 0;
+        sa.emit_small = (attempt == 0 && !ctx->debug_no_raster) ? 1 : 0;
         TSP_HIP(hipEventRecord(ctx->ev[2], st));
         if (WCr == 1) hipLaunchKernelGGL((splat_stream_kernel<MODE, 1>), dim3(grid_s), dim3(256), smem_s, st, sa);
         else hipLaunchKernelGGL((splat_stream_kernel<MODE, C>), dim3(grid_s), dim3(256), smem_s, st, sa);
