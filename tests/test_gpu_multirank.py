@@ -70,3 +70,68 @@ def test_two_gpu_sharded_render_matches_single_gpu(tmp_path):
     ctx.close()
     got = np.load(tmp_path / "reduced.npy")
     assert np.allclose(got[..., 0], want[..., 0], rtol=1e-5, atol=0)
+
+
+def _reference_frames(vis):
+    """What the UI layers would ask of a Visualizer: an export-quality image, its colormapped presentation, autorange."""
+    from topsy_amd.drawreason import DrawReason
+    vis.scale = 60.0
+    vis.rotate(0.2, 0.3)
+    vis.render_sph(DrawReason.EXPORT)
+    img = vis._sph.get_image().copy()
+    rgba = vis.get_sph_presentation_image().copy()
+    return img, rgba, dict(vis.colormap.get_parameters())
+
+
+@pytest.mark.parametrize("device_ids", [[0, 0], [0, 0, 0]])
+def test_visualizer_on_several_contexts_of_one_device(device_ids):
+    """The multi-GPU driver behind the Visualizer (topsy_amd/multigpu.py) with every context on device 0 -- RCCL refuses two
+    ranks on one device, so the shards are summed through the host, but everything else is the real path: sharded
+    upload, per-shard load-time reordering, concurrent tsp_render calls from one thread per context, one reduce per
+    frame, colormap / autorange on the first context.  Equals the one-context Visualizer within 1e-5."""
+    import topsy_amd
+    n, R = 200000, 256
+    one = topsy_amd.test(n, render_resolution=R)
+    want_img, want_rgba, want_params = _reference_frames(one)
+    one.close()
+    many = topsy_amd.test(n, render_resolution=R, device_ids=device_ids)
+    ctx = many.particle_buffers.context
+    assert ctx.n_gpus == len(device_ids) and ctx.collective == "host" and ctx.num_particles == n
+    got_img, got_rgba, got_params = _reference_frames(many)
+    assert np.allclose(got_img[..., 0], want_img[..., 0], rtol=1e-5, atol=0)
+    assert abs(got_params["vmin"] - want_params["vmin"]) < 1e-4 and abs(got_params["vmax"] - want_params["vmax"]) < 1e-4
+    assert (np.abs(got_rgba.astype(int) - want_rgba.astype(int)) <= 1).all()
+    # weighted quantity + progressive refinement: the frame is completed by REFINE frames without double counting
+    from topsy_amd.drawreason import DrawReason
+    many.quantity_name = "test-quantity"
+    many._sph._render_progression._recommended_num_particles_to_render = 30000
+    many.draw(DrawReason.CHANGE)
+    guard = 0
+    while many._sph.needs_refine():
+        many.draw(DrawReason.REFINE)
+        guard += 1
+        assert guard < 200
+    done = many._sph.get_image().copy()
+    many.render_sph(DrawReason.EXPORT)
+    exp = many._sph.get_image()
+    assert np.allclose(done[..., 0], exp[..., 0], rtol=2e-5, atol=0)
+    many.close()
+
+
+def test_visualizer_two_gpus_rccl():
+    """topsy_amd.test(n, n_gpus=2): two devices driven from one process, RCCL sum-reduce over xGMI.  Skipped on a
+    single-GPU box."""
+    import topsy_amd
+    from topsy_amd import _native
+    if _native.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    n, R = 2_000_000, 512
+    one = topsy_amd.test(n, render_resolution=R)
+    want_img, want_rgba, _ = _reference_frames(one)
+    one.close()
+    two = topsy_amd.test(n, render_resolution=R, n_gpus=2)
+    assert two.particle_buffers.context.collective == "rccl"
+    got_img, got_rgba, _ = _reference_frames(two)
+    assert np.allclose(got_img[..., 0], want_img[..., 0], rtol=1e-5, atol=0)
+    assert (np.abs(got_rgba.astype(int) - want_rgba.astype(int)) <= 1).all()
+    two.close()

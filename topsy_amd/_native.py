@@ -294,6 +294,12 @@ class Context:
         _check(self._lib.tsp_measure_read_bandwidth(self._h, nbytes, iters, ctypes.byref(g)))
         return g.value
 
+    n_gpus = 1
+
+    def end_frame(self, root=0):
+        """Frame boundary of the render loop: nothing to exchange on one GPU (multigpu.MultiGpuContext sums the shards here)."""
+        return 0.0
+
     # ---- colormap -------------------------------------------------------------------------
     def colormap_scalar(self, lut_rgba, vmin, vmax, log, weighted):
         lut = _f32(lut_rgba, name="lut")

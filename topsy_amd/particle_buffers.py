@@ -18,7 +18,7 @@ _UNSET = object()
 
 
 class ParticleBuffers:
-    def __init__(self, loader, resolution, device_id=0, max_draw_calls_per_buffer=1):
+    def __init__(self, loader, resolution, device_id=0, max_draw_calls_per_buffer=1, device_ids=None):
         self._loader = loader
         self.quantity_name = None
         self._quantity_on_device = _UNSET
@@ -27,8 +27,13 @@ class ParticleBuffers:
         self._max_draw_calls_per_buffer = max_draw_calls_per_buffer
         self.block_boundaries = None          # stratum offsets when the library reordered the particles
         # one 4-channel-capable context serves SPH, DepthSPH and RGBSPH (the active channel count
-        # follows the render mode)
-        self.context = _native.Context(resolution, 4, device_id)
+        # follows the render mode); several devices: one context each behind the same interface, the particles
+        # sharded by index range and the image summed once per frame (multigpu.py)
+        if device_ids is not None and len(device_ids) > 1:
+            from . import multigpu
+            self.context = multigpu.MultiGpuContext(resolution, 4, device_ids)
+        else:
+            self.context = _native.Context(resolution, 4, device_id if not device_ids else device_ids[0])
         self.context.set_kernel_mips(kernel_lut.kernel_mips())
         self._upload_geometry()
 

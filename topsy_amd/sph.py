@@ -117,6 +117,8 @@ class SPH:
             self._render_timer.add_block(ms)
             rp.end_block(self._render_timer.total_time_in_frame())
             clear = False
+        # several GPUs: the one exchange step of the frame, the sum-reduce of the partial images (no-op on one GPU)
+        self._render_timer.add_block(self._context.end_frame())
         self._render_timer.end_frame()
         self.last_render_mass_scale = rp.end_frame_get_scalefactor()
         mean = self._render_timer.running_mean_duration

@@ -27,19 +27,25 @@ class VisualizerBase:
 
     def __init__(self, data_loader_class=loader.TestDataLoader, data_loader_args=(), data_loader_kwargs={},
                  *, render_resolution=config.DEFAULT_RESOLUTION, periodic_tiling=False,
-                 colormap_name=config.DEFAULT_COLORMAP, canvas_class=None, render_mode="univariate", device_id=0):
+                 colormap_name=config.DEFAULT_COLORMAP, canvas_class=None, render_mode="univariate", device_id=0,
+                 n_gpus=None, device_ids=None):
+        """n_gpus / device_ids: render on several GPUs of this node from this one process -- the particles are sharded
+        by index range, every render block runs on all shards at once and the frame ends with one RCCL sum-reduce of the
+        image onto the first device (topsy_amd/multigpu.py); everything else (colormap, autorange, exports) is unchanged."""
         self._render_resolution = render_resolution
         self._sph = None
         self._colormap = None
-        self._device_id = device_id
+        if device_ids is None and n_gpus is not None and n_gpus > 1:
+            device_ids = list(range(device_id, device_id + n_gpus))
+        self._device_id = device_id if not device_ids else device_ids[0]
         self._prevent_sph_rendering = False
         self._validate_render_mode(render_mode)
         self._render_mode = render_mode
         self.canvas_format = self._render_mode_to_canvas_format(render_mode)
         self.data_loader = data_loader_class(self.device, *data_loader_args, **data_loader_kwargs)
         self.particle_buffers = particle_buffers.ParticleBuffers(
-            self.data_loader, render_resolution, device_id,
-            self.data_loader.get_render_progression().get_max_particle_regions_per_block())
+            self.data_loader, render_resolution, self._device_id,
+            self.data_loader.get_render_progression().get_max_particle_regions_per_block(), device_ids=device_ids)
         self.periodicity_scale = self.data_loader.get_periodicity_scale()
         self._periodic_tiling = periodic_tiling
         if periodic_tiling and not self.periodicity_scale:
