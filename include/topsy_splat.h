@@ -120,6 +120,20 @@ int tsp_reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *
  * Returns the number of values written (<= capacity), 0 when the particles were never reordered. */
 int tsp_get_strata_offsets(tsp_context *ctx, int64_t *offsets_out, int capacity);
 
+/* View culling on the library's own ordering (the role of the reference's CellLayout and
+ * RenderProgressionWithCells._map_logical_range_to_actual_ranges, src/topsy/cell_layout.py:26-31,63-113,
+ * src/topsy/progressive_render.py:152-187,207-220).  Inside a stratum the Morton order stores the particles of every cell
+ * of a cells_per_axis^3 grid over the snapshot's bounding box as ONE contiguous run.  tsp_get_cell_layout reports the grid
+ * (cells_per_axis = 2^k, the largest k <= 4 with >= 16 particles per (stratum, cell) on average; cell (cx, cy, cz) covers
+ * box_lo + (cx, cy, cz) * cell_width ... + cell_width per axis), tsp_get_cell_offsets the first index of every run:
+ * n_strata * cells_per_axis^3 + 1 ascending int64 values, entry s * cells^3 + code for stratum s and Morton cell code
+ * (bit 3 j of the code = bit j of cx, bit 3 j + 1 = bit j of cy, bit 3 j + 2 = bit j of cz), the last entry = n.
+ * The host selects the cells that meet the view sphere and hands tsp_render the (start, len) runs of those cells.
+ * tsp_get_cell_offsets returns the number of values written (<= capacity), 0 when the particles were never reordered. */
+int tsp_get_cell_layout(tsp_context *ctx, int *n_strata_out, int *cells_per_axis_out, float *box_lo_out /*3*/,
+                        float *cell_width_out /*3*/);
+int64_t tsp_get_cell_offsets(tsp_context *ctx, int64_t *offsets_out, int64_t capacity);
+
 /* Copy resident particle arrays back (testing / fixtures). Any pointer may be NULL. */
 int tsp_download_particles(tsp_context *ctx, float *x, float *y, float *z, float *h, float *mass,
                            float *q, float *r, float *g, float *b);

@@ -44,6 +44,9 @@ class FakeContext:
             return np.empty(0, dtype=np.int64)
         return np.linspace(0, self.n, self.n_strata + 1).astype(np.int64)
 
+    def cell_layouts(self):
+        return []
+
     @property
     def num_particles(self):
         return self.n

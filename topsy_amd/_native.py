@@ -59,6 +59,8 @@ SIGNATURES = {
                                               ctypes.c_float, ctypes.c_int, ctypes.c_int]),
     "tsp_reorder_spatial": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_uint64, _i64p]),
     "tsp_get_strata_offsets": (ctypes.c_int, [_ctx, _i64p, ctypes.c_int]),
+    "tsp_get_cell_layout": (ctypes.c_int, [_ctx, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), _fp, _fp]),
+    "tsp_get_cell_offsets": (ctypes.c_int64, [_ctx, _i64p, ctypes.c_int64]),
     "tsp_download_particles": (ctypes.c_int, [_ctx] + [_fp] * 9),
     "tsp_num_particles": (ctypes.c_int64, [_ctx]),
     "tsp_render": (ctypes.c_int, [_ctx, _fp, ctypes.c_float, _i64p, _i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -216,6 +218,26 @@ class Context:
         buf = np.empty(4098, dtype=np.int64)
         k = int(self._lib.tsp_get_strata_offsets(self._h, buf.ctypes.data_as(_i64p), len(buf)))
         return buf[:k].copy()
+
+    def cell_layout(self):
+        """Cells of the library's load-time ordering (tsp_get_cell_layout / tsp_get_cell_offsets) or None when the
+        particles were never reordered: dict(n_strata, cells_per_axis, box_lo (3,), cell_width (3,), offsets (n_strata *
+        cells_per_axis^3 + 1,))."""
+        ns, ca = ctypes.c_int(0), ctypes.c_int(0)
+        lo, width = np.zeros(3, dtype=np.float32), np.zeros(3, dtype=np.float32)
+        if self._lib.tsp_get_cell_layout(self._h, ctypes.byref(ns), ctypes.byref(ca), _ptr(lo), _ptr(width)) < 0:
+            return None
+        buf = np.empty(ns.value * ca.value ** 3 + 1, dtype=np.int64)
+        k = int(self._lib.tsp_get_cell_offsets(self._h, buf.ctypes.data_as(_i64p), len(buf)))
+        if k != len(buf):
+            raise BackendError("tsp_get_cell_offsets returned an unexpected number of values")
+        return {"n_strata": ns.value, "cells_per_axis": ca.value, "box_lo": lo.astype(np.float64),
+                "cell_width": width.astype(np.float64), "offsets": buf}
+
+    def cell_layouts(self):
+        """[cell_layout()] or [] -- the list form that a multi-GPU context fills with one entry per shard."""
+        lay = self.cell_layout()
+        return [] if lay is None else [lay]
 
     def download_particles(self, names=("x", "y", "z", "h", "mass")):
         order = ("x", "y", "z", "h", "mass", "q", "r", "g", "b")

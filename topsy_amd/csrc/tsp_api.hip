@@ -86,6 +86,8 @@ static void free_particles(tsp_context *ctx) {
     p.perm = nullptr;
     p.n = 0;
     ctx->strata_offsets.clear();
+    ctx->cell_offsets.clear();
+    ctx->cell_bits = 0;
 }
 
 }  // namespace tsp
@@ -307,6 +309,25 @@ int tsp_get_strata_offsets(tsp_context *ctx, int64_t *offsets_out, int capacity)
     if (!ctx || !offsets_out || capacity <= 0) return 0;
     const int n = (int)std::min<size_t>(ctx->strata_offsets.size(), (size_t)capacity);
     for (int i = 0; i < n; ++i) offsets_out[i] = ctx->strata_offsets[(size_t)i];
+    return n;
+}
+
+int tsp_get_cell_layout(tsp_context *ctx, int *n_strata_out, int *cells_per_axis_out, float *box_lo_out, float *cell_width_out) {
+    TSP_REQUIRE(ctx && n_strata_out && cells_per_axis_out && box_lo_out && cell_width_out, TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(!ctx->cell_offsets.empty(), TSP_ESTATE, "the particles were never reordered (tsp_reorder_spatial)");
+    *n_strata_out = (int)ctx->strata_offsets.size() - 1;
+    *cells_per_axis_out = 1 << ctx->cell_bits;
+    for (int a = 0; a < 3; ++a) {
+        box_lo_out[a] = ctx->cell_lo[a];
+        cell_width_out[a] = ctx->cell_width[a];
+    }
+    return TSP_OK;
+}
+
+int64_t tsp_get_cell_offsets(tsp_context *ctx, int64_t *offsets_out, int64_t capacity) {
+    if (!ctx || !offsets_out || capacity <= 0) return 0;
+    const int64_t n = std::min<int64_t>((int64_t)ctx->cell_offsets.size(), capacity);
+    for (int64_t i = 0; i < n; ++i) offsets_out[i] = ctx->cell_offsets[(size_t)i];
     return n;
 }
 

@@ -188,16 +188,18 @@ __global__ void gather_u32_kernel(const uint32_t *__restrict__ src, const uint32
         dst[i] = src[idx[i]];
 }
 
-// offsets[s] = first index whose stratum (key >> 48) is >= s, for s = 0 .. n_strata (offsets[n_strata] = n)
-__global__ void strata_offsets_kernel(const uint64_t *__restrict__ keys, int64_t n, int n_strata, int64_t *__restrict__ offsets) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s > n_strata) return;
+// offsets[e] = first index whose key prefix (key >> shift) is >= e, for e = 0 .. n_entries - 1 (offsets[n_entries - 1] = n when
+// the last entry is one past the largest prefix).  shift = 48: prefix = stratum; shift = 48 - 3 k: prefix = (stratum, cell
+// code of a (2^k)^3 grid) -- the leading 3 k bits of a Morton key are the key of the particle's cell.
+__global__ void key_prefix_offsets_kernel(const uint64_t *__restrict__ keys, int64_t n, int64_t n_entries, int shift, int64_t *__restrict__ offsets) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_entries) return;
     int64_t lo = 0, hi = n;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if ((int64_t)(keys[mid] >> 48) < (int64_t)s) lo = mid + 1; else hi = mid;
+        if ((int64_t)(keys[mid] >> shift) < e) lo = mid + 1; else hi = mid;
     }
-    offsets[s] = lo;
+    offsets[e] = lo;
 }
 
 int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out) {
@@ -240,12 +242,32 @@ int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm
         // stratum boundaries in the new order (keys2 holds the sorted keys)
         DeviceScratch d_off;
         TSP_HIP(d_off.alloc((size_t)(n_strata + 1) * sizeof(int64_t)));
-        hipLaunchKernelGGL(strata_offsets_kernel, dim3((n_strata + 256) / 256), dim3(256), 0, st, keys2.as<uint64_t>(), n,
-                           n_strata, d_off.as<int64_t>());
+        hipLaunchKernelGGL(key_prefix_offsets_kernel, dim3((n_strata + 256) / 256), dim3(256), 0, st, keys2.as<uint64_t>(), n,
+                           (int64_t)n_strata + 1, 48, d_off.as<int64_t>());
         TSP_HIP(hipGetLastError());
         ctx->strata_offsets.assign((size_t)n_strata + 1, 0);
         TSP_HIP(hipMemcpyAsync(ctx->strata_offsets.data(), d_off.p, (size_t)(n_strata + 1) * sizeof(int64_t),
                                hipMemcpyDeviceToHost, st));
+        // Cells for view culling (the role of the reference's CellLayout, src/topsy/cell_layout.py): inside a stratum the
+        // Morton order stores every cell of a (2^k)^3 grid over the bounding box as ONE contiguous run; k <= 4 (the
+        // reference's 16^3 cells, config.py:27), fewer for small snapshots (>= 16 particles per (stratum, cell) on average).
+        // The host merges runs separated by short gaps, so fine cells do not fragment kernel S's 512-particle chunks.
+        int k = 0;
+        while (k < 4 && n / ((int64_t)n_strata << (3 * (k + 1))) >= 16) ++k;
+        const int64_t n_entries = ((int64_t)n_strata << (3 * k)) + 1;
+        DeviceScratch d_cell;
+        TSP_HIP(d_cell.alloc((size_t)n_entries * sizeof(int64_t)));
+        hipLaunchKernelGGL(key_prefix_offsets_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, st, keys2.as<uint64_t>(), n,
+                           n_entries, 48 - 3 * k, d_cell.as<int64_t>());
+        TSP_HIP(hipGetLastError());
+        ctx->cell_offsets.assign((size_t)n_entries, 0);
+        TSP_HIP(hipMemcpyAsync(ctx->cell_offsets.data(), d_cell.p, (size_t)n_entries * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        ctx->cell_bits = k;
+        for (int a = 0; a < 3; ++a) {
+            ctx->cell_lo[a] = lo[a];
+            // a cell spans 2^(16 - k) quantisation steps of 1 / inv world units each (inv = 0: a degenerate axis, one cell)
+            ctx->cell_width[a] = inv[a] > 0.0f ? (float)(1 << (16 - k)) / inv[a] : 0.0f;
+        }
         TSP_HIP(hipStreamSynchronize(st));
     }
     // permute every resident attribute through one spare buffer

@@ -99,6 +99,9 @@ struct tsp_context {
     size_t sort_tmp_bytes = 0;
     int64_t sort_capacity = 0, sorted_count = 0;
     tsp_stats stats = {};
+    std::vector<int64_t> cell_offsets;     // first index of every (stratum, Morton cell) run of the last reorder_spatial, then n
+    int cell_bits = 0;                     // the cells form a (2^cell_bits)^3 grid over the bounding box
+    float cell_lo[3] = {0, 0, 0}, cell_width[3] = {0, 0, 0};
     std::vector<int64_t> strata_offsets;   // first index of every stratum of the last reorder_spatial, then n
     int mid_attr_extra[3] = {-1, -1, -1};   // per render mode: the debug_extra_lds value kernel M's dynamic-LDS limit was last set for
     uint32_t kernel_attr_done = 0;   // bit per kernel family whose dynamic-LDS limit was raised on this context's device

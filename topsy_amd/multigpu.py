@@ -166,6 +166,16 @@ class MultiGpuContext:
         parts = [o[:-1] + self._bounds[g] for g, o in enumerate(offs) if len(o)]
         return np.concatenate(parts + [self._bounds[-1:]]).astype(np.int64)
 
+    def cell_layouts(self):
+        """One cell grid per shard (each over its own bounding box), offsets shifted to global indices."""
+        out = []
+        for g, lays in enumerate(self._map(lambda g, c: c.cell_layouts() if self._shard(g)[1] > 0 else [])):
+            for lay in lays:
+                lay = dict(lay)
+                lay["offsets"] = np.asarray(lay["offsets"], dtype=np.int64) + self._bounds[g]
+                out.append(lay)
+        return out
+
     def download_particles(self, names=("x", "y", "z", "h", "mass")):
         parts = self._map(lambda g, c: c.download_particles(names) if self._shard(g)[1] > 0 else
                           {k: np.empty(0, dtype=np.float32) for k in names})

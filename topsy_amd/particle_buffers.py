@@ -26,6 +26,7 @@ class ParticleBuffers:
         self._last_ranges = (None, None)
         self._max_draw_calls_per_buffer = max_draw_calls_per_buffer
         self.block_boundaries = None          # stratum offsets when the library reordered the particles
+        self.device_cells = None              # ... and the cells of that ordering (view culling)
         # one 4-channel-capable context serves SPH, DepthSPH and RGBSPH (the active channel count
         # follows the render mode); several devices: one context each behind the same interface, the particles
         # sharded by index range and the image summed once per frame (multigpu.py)
@@ -45,7 +46,7 @@ class ParticleBuffers:
             self._have_rgb = True
             if ld.spatial_order:
                 self.context.reorder_spatial(self._num_strata(ld.count), ld.seed)
-                self.block_boundaries = self.context.strata_offsets()
+                self._note_ordering()
             return
         logger.info("Uploading position+smoothing+mass arrays")
         ps = ld.get_pos_smooth()
@@ -56,7 +57,12 @@ class ParticleBuffers:
         # unbiased for the plain RenderProgression, and later quantity/rgb uploads are permuted by the library.
         if not hasattr(ld, "_cell_layout") and len(ld) > 1:
             self.context.reorder_spatial(self._num_strata(len(ld)), 1337)
-            self.block_boundaries = self.context.strata_offsets()
+            self._note_ordering()
+
+    def _note_ordering(self):
+        from . import cell_layout
+        self.block_boundaries = self.context.strata_offsets()
+        self.device_cells = cell_layout.StratifiedCells.from_context(self.context)
 
     @staticmethod
     def _num_strata(n):

@@ -56,6 +56,8 @@ class SPH:
             boundaries = getattr(visualizer.particle_buffers, "block_boundaries", None)
             if boundaries is not None and hasattr(self._render_progression, "set_block_boundaries"):
                 self._render_progression.set_block_boundaries(boundaries)
+                # view culling on the library's own ordering (per-stratum Morton cell runs)
+                self._render_progression.set_device_cells(getattr(visualizer.particle_buffers, "device_cells", None))
         self.scale = config.DEFAULT_SCALE
         self.min_pixels = 0.0
         self.max_pixels = np.inf
