@@ -106,10 +106,12 @@ def main():
 
     dist = torch = None
     if world > 1:
+        # torch.distributed is the launcher's rendezvous only (the 128-byte RCCL id, barriers, the max-over-ranks time):
+        # a gloo group of host tensors.  The data path's one collective -- the image reduce -- is this library's own RCCL
+        # communicator (tsp_comm_*), so torch never touches the GPU here and there is a single RCCL communicator per rank.
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="gloo")
 
     from topsy_amd import _native, kernel_lut
 
@@ -158,11 +160,10 @@ def main():
         return None
 
     def barrier():
-        # every tsp_* call is synchronous (it returns after its GPU work has completed), so at N = 1 there is nothing
-        # in flight here; at N > 1 the ranks meet and torch's own stream is drained as the contract asks
+        # every tsp_* call is synchronous (it returns after its GPU work has completed: hipStreamSynchronize on the stream
+        # the kernels and the RCCL reduce run on), so nothing is in flight here; at N > 1 the ranks meet
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         frame(False)
@@ -176,7 +177,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -186,7 +187,7 @@ def main():
     ctx.set_option("count_fragments", 0)
     frags = st["n_fragments"]
     if dist is not None:
-        f = torch.tensor([float(frags)], dtype=torch.float64, device="cuda")
+        f = torch.tensor([float(frags)], dtype=torch.float64)
         dist.all_reduce(f)
         frags = f.item()
 

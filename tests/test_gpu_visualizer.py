@@ -138,7 +138,7 @@ def test_progressive_frames_fold_mass_scale():
     # pretend every block costs 40 ms of GPU time, so the 1/30 s budget admits one block per frame
     timer = v._sph._render_timer
     real_add = timer.add_block
-    timer.add_block = lambda ms: real_add(40.0)
+    timer.add_block = lambda ms, wall_seconds=None: real_add(40.0)
     v.invalidate()
     v.draw(DrawReason.CHANGE)
     # the library reordered the particles into strata: the block was rounded to whole strata (unbiased sample)
@@ -172,7 +172,7 @@ def test_depth_query_between_progressive_frames():
     rp._recommended_num_particles_to_render = 50000
     timer = v._sph._render_timer
     real_add = timer.add_block
-    timer.add_block = lambda ms: real_add(40.0)        # one block per interactive frame
+    timer.add_block = lambda ms, wall_seconds=None: real_add(40.0)        # one block per interactive frame
     v.invalidate()
     v.draw(DrawReason.CHANGE)
     assert v._pending_draw == DrawReason.REFINE and v._sph.needs_refine()
@@ -336,7 +336,7 @@ def test_cell_progression_multi_range_blocks():
     rp._recommended_num_particles_to_render = 7000
     timer = v._sph._render_timer
     real_add = timer.add_block
-    timer.add_block = lambda ms: real_add(40.0)           # one block per frame
+    timer.add_block = lambda ms, wall_seconds=None: real_add(40.0)           # one block per frame
     v.invalidate()
     v.draw(DrawReason.CHANGE)
     starts, lens = v.particle_buffers.current_ranges()
@@ -380,7 +380,7 @@ def test_first_interactive_block_is_a_whole_stratum():
     assert abs(np.diff(bounds) / (5_000_000 / 32) - 1.0).max() < 0.02        # uniform random strata
     timer = v._sph._render_timer
     real_add = timer.add_block
-    timer.add_block = lambda ms: real_add(40.0)           # one block per frame
+    timer.add_block = lambda ms, wall_seconds=None: real_add(40.0)           # one block per frame
     rp._recommended_num_particles_to_render = 100000      # the reference's first-frame guess (config.py:7)
     v.invalidate()
     v.draw(DrawReason.CHANGE)
@@ -506,7 +506,7 @@ def test_view_culling_on_the_device_ordering():
     assert rp.get_fraction_volume_selected() > 0.5
     timer = v._sph._render_timer
     real_add = timer.add_block
-    timer.add_block = lambda ms: real_add(40.0)           # one block per interactive frame
+    timer.add_block = lambda ms, wall_seconds=None: real_add(40.0)           # one block per interactive frame
 
     def zoom(centre, scale):
         v.scale = scale

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     // float32 accumulators hold at most FOLD_EVERY footprints (rounding error ~ sqrt(n) * 2^-24 relative: < 2e-6 at
     // the worst pixel), then go to the float64 render target; second-level register totals (as kernel H keeps) would
     // cost HR * W more VGPRs and spill here
-    constexpr int FOLD_EVERY = 512;
+    constexpr int FOLD_EVERY = TSP_FOLD_EVERY;
     float acc[HR * W][NACC];
 #pragma unroll
     for (int p = 0; p < HR * W; ++p)
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
     float pxc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) pxc[b] = (sx + 32 * b + li < R) ? (float)(sx + 32 * b + li) + 0.5f : __builtin_inff();
-    constexpr int FOLD_EVERY = 512;                        // as kernel H2: float32 accumulators hold <= 512 footprints
+    constexpr int FOLD_EVERY = TSP_FOLD_EVERY;              // as kernel H2: float32 accumulators hold <= 512 footprints
     f32x16 acc[NACC][NB];
 #pragma unroll
     for (int c = 0; c < NACC; ++c)

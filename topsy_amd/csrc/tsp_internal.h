@@ -107,7 +107,7 @@ struct tsp_context {
     uint32_t kernel_attr_done = 0;   // bit per kernel family whose dynamic-LDS limit was raised on this context's device
     bool count_fragments = false;
     // pipeline tuning (tsp_set_option)
-    float p_small = 13.5f;             // footprints narrower than this many pixels are splatted by kernel S (mips 3 and 2; <= 22.6)
+    float p_small = 16.0f;             // footprints narrower than this many pixels are splatted by kernel S (mips 3 and 2; <= 16: its texel columns are packed 16 x 4 bits)
     float p_mega = 512.0f;            // footprints at least this wide go to kernel H3 (matrix cores); 0 = all to H2
     int huge_variant = 1;             // 0: kernel H (per-pixel gather, A/B only), 1: kernels H2 (64x16 strips) + H3, 2: H2 with 64x32 strips (density)
     int mid_split = 128, huge_split = 0, mega_split = 0;  // workgroups per image tile (0 = auto)

@@ -6,8 +6,16 @@
 namespace tsp {
 
 
-constexpr int CHUNK = 512;           // particles per chunk
-constexpr int KPT = CHUNK / 256;     // particles per thread per chunk
+#ifndef TSP_S_BLOCK
+#define TSP_S_BLOCK 256
+#endif
+#ifndef TSP_S_KPT
+#define TSP_S_KPT 2
+#endif
+constexpr int SBLOCK = TSP_S_BLOCK;  // threads per workgroup of kernel S
+constexpr int SWAVES = SBLOCK / 64;
+constexpr int KPT = TSP_S_KPT;       // particles per thread per chunk
+constexpr int CHUNK = SBLOCK * KPT;  // particles per chunk
 constexpr int TILE = 64;             // image tile edge of kernel H (and tile width of kernel M)
 // tile height of kernel M by the number of channels in its LDS tile: 64 x 32 pixels for a density render; 64 x 16 with
 // two or three channels, so that two (rgb) or three workgroups still fit a CU's LDS (rgb: M 31.9 -> 21.0 ms)
@@ -38,6 +46,9 @@ __device__ __forceinline__ void latomic_add(double *addr, float v) {
     __hip_atomic_fetch_add(addr, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+#ifndef TSP_FOLD_EVERY
+#define TSP_FOLD_EVERY 512     // footprints a float32 accumulator of kernels H2 / H3 holds before it goes to the float64 target
+#endif
 #ifndef TSP_HDEAL
 #define TSP_HDEAL 16
 #endif

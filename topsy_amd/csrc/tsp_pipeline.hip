@@ -106,22 +106,22 @@ struct StreamArgs {
 // WC = channels kept in the LDS window: 1 for a density-only render (channel 1 is identically 0:
 // half the LDS and half the atomics), else the image's channel count.
 template <int MODE, int WC>
-__global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs a) {
+__global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;      // extra weights per record
     constexpr int WIN = WinSize<WC>::value;
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
     double *win = smem_d;                                            // [WC][WIN*WIN]
     float *T23 = reinterpret_cast<float *>(win + WC * WIN * WIN);    // mip levels 2 (16x16) and 3 (8x8): 320 floats
-    __shared__ unsigned s_red[4][2], s_mbb[4][2];
-    __shared__ int s_cnt[4];
+    __shared__ unsigned s_red[SWAVES][2], s_mbb[SWAVES][2];
+    __shared__ int s_cnt[SWAVES];
     __shared__ long long s_base[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const Camera &cam = a.cam;
     const int R = cam.R;
-    for (int i = tid; i < WC * WIN * WIN; i += 256) win[i] = 0.0;
-    for (int i = tid; i < 320; i += 256) T23[i] = a.mips[5120 + i];
+    for (int i = tid; i < WC * WIN * WIN; i += SBLOCK) win[i] = 0.0;
+    for (int i = tid; i < 320; i += SBLOCK) T23[i] = a.mips[5120 + i];
     __syncthreads();
 
     // window state (uniform): origin and the dirty rectangle (window coordinates, inclusive)
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
         // one global atomic per touched pixel and channel; only the dirty rectangle is visited
         if (dx1 >= dx0) {
             const int fw = dx1 - dx0 + 1, fn = fw * (dy1 - dy0 + 1);
-            for (int idx = tid; idx < fn; idx += 256) {
+            for (int idx = tid; idx < fn; idx += SBLOCK) {
                 const int jj = idx / fw;
                 const int wy = dy0 + jj, wx = dx0 + (idx - jj * fw);
                 const int gx = wox + wx, gy = woy + wy;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
     auto load_chunk = [&](int64_t first, int cnt) {
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            const int li = k * 256 + tid;
+            const int li = k * SBLOCK + tid;
 #pragma unroll
             for (int t = 0; t < NATTR; ++t) L[k][t] = 0.0f;
             if (li < cnt) {
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
         int my_counts = 0;                           // mid records | huge records << 16 of this lane
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            const int li = k * 256 + tid;
+            const int li = k * SBLOCK + tid;
             cls[k] = CLS_NONE;
             pcx[k] = pcy[k] = PP[k] = invP[k] = w0[k] = w1[k] = w2[k] = 0.0f;
             xr[k] = yr[k] = 0u;
@@ -258,8 +258,9 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
         s_lo = wave_pk_min_u16(s_lo); s_hi = wave_pk_max_u16(s_hi);
         if (lane == 0) { s_red[wv][0] = s_lo; s_red[wv][1] = s_hi; }
         __syncthreads();
-        s_lo = pk_min_u16(pk_min_u16(s_red[0][0], s_red[1][0]), pk_min_u16(s_red[2][0], s_red[3][0]));
-        s_hi = pk_max_u16(pk_max_u16(s_red[0][1], s_red[1][1]), pk_max_u16(s_red[2][1], s_red[3][1]));
+        s_lo = s_red[0][0]; s_hi = s_red[0][1];
+#pragma unroll
+        for (int w = 1; w < SWAVES; ++w) { s_lo = pk_min_u16(s_lo, s_red[w][0]); s_hi = pk_max_u16(s_hi, s_red[w][1]); }
         if ((s_hi & 0xffffu) >= (s_lo & 0xffffu)) {          // the chunk has small footprints
             const int ix0 = (int)(s_lo & 0xffffu), iy0 = (int)(s_lo >> 16), ix1 = (int)(s_hi & 0xffffu), iy1 = (int)(s_hi >> 16);
             const bool inside = ix0 >= wox && ix1 < wox + WIN && iy0 >= woy && iy1 < woy + WIN;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
         __syncthreads();
         int counts_before = 0, counts_total = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < SWAVES; ++w) {
             if (w < wv) counts_before += s_cnt[w];
             counts_total += s_cnt[w];
         }
@@ -312,8 +313,9 @@ __global__ __launch_bounds__(256, TSP_S_OCC) void splat_stream_kernel(StreamArgs
             if (mid_total) {
                 // covered-pixel bounds [x0, x1] x [y0, y1] stored as (x0, y0, x1 + 1, y1 + 1): kernel M's tile test
                 // bb.x < tile_x1 && bb.z > tile_x0 is then exact for integer tile edges
-                const unsigned lo = pk_min_u16(pk_min_u16(s_mbb[0][0], s_mbb[1][0]), pk_min_u16(s_mbb[2][0], s_mbb[3][0]));
-                const unsigned hi = pk_max_u16(pk_max_u16(s_mbb[0][1], s_mbb[1][1]), pk_max_u16(s_mbb[2][1], s_mbb[3][1]));
+                unsigned lo = s_mbb[0][0], hi = s_mbb[0][1];
+#pragma unroll
+                for (int w = 1; w < SWAVES; ++w) { lo = pk_min_u16(lo, s_mbb[w][0]); hi = pk_max_u16(hi, s_mbb[w][1]); }
                 a.seg_bbox[c] = make_float4((float)(lo & 0xffffu), (float)(lo >> 16), (float)((hi & 0xffffu) + 1u), (float)((hi >> 16) + 1u));
             }
         }
@@ -864,8 +866,8 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         sa.cnt = ctx->counters; sa.p_small = ctx->p_small; sa.p_mega = (ctx->huge_variant != 0 && MODE != TSP_MODE_RGB && ctx->p_mega > 0.0f) ? ctx->p_mega : __builtin_inff(); sa.count_frag = ctx->count_fragments ? 1 : 0;
         sa.emit_small = (attempt == 0 && !ctx->debug_no_raster) ? 1 : 0;
         TSP_HIP(hipEventRecord(ctx->ev[2], st));
-        if (WCr == 1) hipLaunchKernelGGL((splat_stream_kernel<MODE, 1>), dim3(grid_s), dim3(256), smem_s, st, sa);
-        else hipLaunchKernelGGL((splat_stream_kernel<MODE, C>), dim3(grid_s), dim3(256), smem_s, st, sa);
+        if (WCr == 1) hipLaunchKernelGGL((splat_stream_kernel<MODE, 1>), dim3(grid_s), dim3(SBLOCK), smem_s, st, sa);
+        else hipLaunchKernelGGL((splat_stream_kernel<MODE, C>), dim3(grid_s), dim3(SBLOCK), smem_s, st, sa);
         TSP_HIP(hipGetLastError());
         TSP_HIP(hipEventRecord(ctx->ev[3], st));
         // the record counts size the two tile launches (and reveal a list overflow)

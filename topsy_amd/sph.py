@@ -113,14 +113,16 @@ class SPH:
         buffers = self._visualizer.particle_buffers
         clear = rp.start_frame(draw_reason)
         while block := rp.get_block(self._render_timer.total_time_in_frame()):
-            buffers.update_particle_ranges(*block)
-            starts, lens = buffers.current_ranges()
-            ms = self._context.render(M, sf, starts, lens, clear=clear, mode=self._mode, flags=self.pipeline_flags)
-            self._render_timer.add_block(ms)
+            # a block is charged its wall-clock time (host work included), as the reference's TimeGpuOperation does
+            with self._render_timer.block() as timed:
+                buffers.update_particle_ranges(*block)
+                starts, lens = buffers.current_ranges()
+                timed.gpu_ms = self._context.render(M, sf, starts, lens, clear=clear, mode=self._mode, flags=self.pipeline_flags)
             rp.end_block(self._render_timer.total_time_in_frame())
             clear = False
         # several GPUs: the one exchange step of the frame, the sum-reduce of the partial images (no-op on one GPU)
-        self._render_timer.add_block(self._context.end_frame())
+        with self._render_timer.block() as timed:
+            timed.gpu_ms = self._context.end_frame()
         self._render_timer.end_frame()
         self.last_render_mass_scale = rp.end_frame_get_scalefactor()
         mean = self._render_timer.running_mean_duration
