@@ -351,7 +351,7 @@ def test_record_list_overflow_replay_with_mega_records(native, mips, label, h_va
     n, R = 1_100_000, 1024
     rs = np.random.RandomState(8)
     pos = (rs.normal(size=(n, 3)) * 60.0).astype(np.float32)
-    h = rs.choice(np.asarray(h_values, dtype=np.float32), size=n)          # P = 2 h R / scale = 204.8 px (H2) or 614.4 px (H3)
+    h = rs.choice(np.asarray(h_values, dtype=np.float32), size=n)          # P = 2 h R / scale = 204.8 px (H2; rgb: H3) or 614.4 px (H3)
     m = rs.uniform(0.5, 1.5, n).astype(np.float32)
     rgb = rs.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32)
     M, sf = camera(200.0)
@@ -364,8 +364,10 @@ def test_record_list_overflow_replay_with_mega_records(native, mips, label, h_va
         st = c2.stats()
         a = c2.read_image().astype(np.float64)
         assert st["n_huge"] > 16 * 65536 and st["n_small"] == 0 and st["n_mid"] == 0
-        if mode != native.MODE_RGB:              # rgb keeps every footprint >= 64 px on kernel H (no mega class)
-            assert st["n_mega"] > 0
+        assert st["n_mega"] > 0
+        if mode == native.MODE_RGB:              # rgb: kernel H3 from 128 px, so both widths are mega records
+            assert st["n_mega"] == st["n_huge"]
+        else:                                    # density: from 512 px
             assert (st["n_mega"] == st["n_huge"]) == (label == "all-mega")
         assert st["n_huge"] + st["n_culled"] == n
         c2.render(M, sf, mode=mode)              # second frame: the lists are large enough now

@@ -689,9 +689,15 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         else ctx->stream_blocks_per_cu = value > 0 ? (int)value : 1;
         return TSP_OK;
     }
-    if (!strcmp(name, "p_mega_px")) {         // class boundary H2 / H3 in pixels (>= 64; 0 = no H3)
-        TSP_REQUIRE(value == 0 || (value >= 64 && value <= (1 << 20)), TSP_EINVAL, "p_mega_px out of range");
-        ctx->p_mega = (float)value;
+    if (!strcmp(name, "p_mega_px") || !strcmp(name, "p_mega2_px") || !strcmp(name, "p_mega_rgb_px")) {
+        // class boundary H2 (rgb: H) / H3 in pixels (>= 64; 0 = no H3) for density / two-channel / rgb renders
+        TSP_REQUIRE(value == 0 || (value >= 64 && value <= (1 << 20)), TSP_EINVAL, "%s out of range", name);
+        (name[6] == '2' ? ctx->p_mega2 : (name[6] == '_' && name[7] == 'r' ? ctx->p_mega_rgb : ctx->p_mega)) = (float)value;
+        return TSP_OK;
+    }
+    if (!strcmp(name, "rgb_mega_variant")) {
+        TSP_REQUIRE(value >= 0 && value <= 3, TSP_EINVAL, "rgb_mega_variant out of range");
+        ctx->rgb_mega_variant = (int)value;
         return TSP_OK;
     }
     if (!strcmp(name, "huge_variant")) {

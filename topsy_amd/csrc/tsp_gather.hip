@@ -743,18 +743,49 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
             }
             int rowoff = (r0 + kh) * (PT_STRIDE * 4);   // this lane's texel row of the current k-step (bytes)
             int kk = kh;
-            for (int m = 0; m < nsteps; ++m) {
-                const float A = (rel == kk) ? gy : ((rel + 1 == kk) ? fy : 0.0f);
+            if constexpr (NACC == 1) {
+                for (int m = 0; m < nsteps; ++m) {
+                    const float A = (rel == kk) ? gy : ((rel + 1 == kk) ? fy : 0.0f);
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const float *t = reinterpret_cast<const float *>(PTb + rowoff + caddr[b]);
-                    const float L = __builtin_fmaf(t[1], fxs[b], t[0] * gxs[b]);
-                    acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, (NACC == 1) ? L : L * w0, acc[0][b], 0, 0, 0);
-                    if (NACC >= 2) acc[NACC >= 2 ? 1 : 0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, L * w1, acc[NACC >= 2 ? 1 : 0][b], 0, 0, 0);
-                    if (NACC >= 3) acc[NACC - 1][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, L * w2, acc[NACC - 1][b], 0, 0, 0);
+                    for (int b = 0; b < NB; ++b) {
+                        const float *t = reinterpret_cast<const float *>(PTb + rowoff + caddr[b]);
+                        const float L = __builtin_fmaf(t[1], fxs[b], t[0] * gxs[b]);
+                        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, L, acc[0][b], 0, 0, 0);
+                    }
+                    kk += 2;
+                    rowoff += 2 * PT_STRIDE * 4;
                 }
-                kk += 2;
-                rowoff += 2 * PT_STRIDE * 4;
+            } else {
+                // Several channels share the kernel image of the footprint: the matrix cores form it ONCE in a scratch
+                // accumulator (one MFMA per k-step and block instead of one per channel), then every channel takes its multiple of
+                // it on the VALU (16 FMAs per channel and block) -- rgb: a third of the MFMAs.
+                f32x16 kimg[NB];
+                for (int m = 0; m < nsteps; ++m) {
+                    const float A = (rel == kk) ? gy : ((rel + 1 == kk) ? fy : 0.0f);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const float *t = reinterpret_cast<const float *>(PTb + rowoff + caddr[b]);
+                        const float L = __builtin_fmaf(t[1], fxs[b], t[0] * gxs[b]);
+                        if (m == 0) {
+                            f32x16 zero;
+#pragma unroll
+                            for (int v = 0; v < 16; ++v) zero[v] = 0.0f;
+                            kimg[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, L, zero, 0, 0, 0);
+                        } else {
+                            kimg[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, L, kimg[b], 0, 0, 0);
+                        }
+                    }
+                    kk += 2;
+                    rowoff += 2 * PT_STRIDE * 4;
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        acc[0][b][v] = __builtin_fmaf(kimg[b][v], w0, acc[0][b][v]);
+                        acc[NACC >= 2 ? 1 : 0][b][v] = __builtin_fmaf(kimg[b][v], w1, acc[NACC >= 2 ? 1 : 0][b][v]);
+                        if (NACC >= 3) acc[NACC - 1][b][v] = __builtin_fmaf(kimg[b][v], w2, acc[NACC - 1][b][v]);
+                    }
             }
             if (++since_fold == FOLD_EVERY) { since_fold = 0; flush(); }
         }
@@ -811,7 +842,12 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
     TSP_HIP(hipEventRecord(ctx->ev[10], st));
     if (n_mega > 0) {                           // kernel H3 (matrix cores): P >= p_mega, the tail end of the huge list
         ta.geom = mega_geom; ta.w = mega_w; ta.n_records = n_mega;
-        if (second_channel) rc = launch_mega<MODE, 2, 2, 4>(ctx, ta, n_mega);      // 64 accumulator registers at 4 waves/SIMD (3: 10.2 vs 9.9 ms)
+        if constexpr (MODE == TSP_MODE_RGB) {
+            // three accumulator sets (96 registers for a 64 x 32 strip): 2-3 waves per SIMD of the 512-entry register file
+            if (ctx->rgb_mega_variant == 1) rc = launch_mega<MODE, 3, 2, 2>(ctx, ta, n_mega);
+            else if (ctx->rgb_mega_variant == 2) rc = launch_mega<MODE, 3, 2, 3>(ctx, ta, n_mega);
+            else rc = launch_mega<MODE, 3, 1, 3>(ctx, ta, n_mega);
+        } else if (second_channel) rc = launch_mega<MODE, 2, 2, 3>(ctx, ta, n_mega);      // 64 accumulator + 32 scratch registers: 3 waves/SIMD (4 would spill)
         else rc = launch_mega<MODE, 1, 2, 4>(ctx, ta, n_mega);   // 4 column blocks per strip and 5-6 waves/SIMD measured no faster
         if (rc) return rc;
     }

@@ -108,7 +108,10 @@ struct tsp_context {
     bool count_fragments = false;
     // pipeline tuning (tsp_set_option)
     float p_small = 16.0f;             // footprints narrower than this many pixels are splatted by kernel S (mips 3 and 2; <= 16: its texel columns are packed 16 x 4 bits)
-    float p_mega = 512.0f;            // footprints at least this wide go to kernel H3 (matrix cores); 0 = all to H2
+    float p_mega = 512.0f;            // density renders: footprints at least this wide go to kernel H3 (matrix cores); 0 = all to H2
+    float p_mega2 = 256.0f;           // the same for two-channel renders (weighted, depth): their H2 pays 5 instead of 2 FMAs per pixel row
+    float p_mega_rgb = 128.0f;        // ... and for rgb (kernel H below, kernel H3 with three accumulator sets above)
+    int rgb_mega_variant = 3;         // rgb: 0 = every footprint >= 64 px on kernel H; 1-3: those >= p_mega on kernel H3 with three accumulator sets
     int huge_variant = 1;             // 0: kernel H (per-pixel gather, A/B only), 1: kernels H2 (64x16 strips) + H3, 2: H2 with 64x32 strips (density)
     int mid_split = 128, huge_split = 0, mega_split = 0;  // workgroups per image tile (0 = auto)
     int stream_blocks_per_cu = 100;  // kernel S grid bound: ~10 chunks per workgroup at 1e8 particles balances dense and sparse chunks

@@ -863,7 +863,10 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         sa.mid_geom = (float4 *)ws.mid_geom; sa.mid_w = (float *)ws.mid_w; sa.mid_capacity = ws.mid_capacity;
         sa.huge_geom = (float4 *)ws.huge_geom; sa.huge_w = (float *)ws.huge_w; sa.huge_capacity = ws.huge_capacity;
         sa.seg_count = ws.seg_count; sa.seg_offset = ws.seg_offset; sa.seg_bbox = ws.seg_bbox;
-        sa.cnt = ctx->counters; sa.p_small = ctx->p_small; sa.p_mega = (ctx->huge_variant != 0 && MODE != TSP_MODE_RGB && ctx->p_mega > 0.0f) ? ctx->p_mega : __builtin_inff(); sa.count_frag = ctx->count_fragments ? 1 : 0;
+        sa.cnt = ctx->counters; sa.p_small = ctx->p_small; {
+            const float pm = (MODE == TSP_MODE_RGB) ? (ctx->rgb_mega_variant > 0 ? ctx->p_mega_rgb : 0.0f) : (second_channel ? ctx->p_mega2 : ctx->p_mega);
+            sa.p_mega = (ctx->huge_variant != 0 && pm > 0.0f) ? pm : __builtin_inff();
+        } sa.count_frag = ctx->count_fragments ? 1 : 0;
         sa.emit_small = (attempt == 0 && !ctx->debug_no_raster) ? 1 : 0;
         TSP_HIP(hipEventRecord(ctx->ev[2], st));
         if (WCr == 1) hipLaunchKernelGGL((splat_stream_kernel<MODE, 1>), dim3(grid_s), dim3(SBLOCK), smem_s, st, sa);
