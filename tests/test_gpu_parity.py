@@ -535,6 +535,12 @@ def test_gather_kernels_fold_their_accumulators(native, mips):
     ctx.set_option("huge_variant", 0)          # and through the round-1 kernel H
     ctx.render(M, sf)
     assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0)
+    ctx.set_option("huge_variant", 3)          # and through kernel H4 (v_mfma_f32_16x16x4_f32 on 64 x 16 strips; experimental)
+    ctx.set_option("count_fragments", 1)
+    ctx.render(M, sf)
+    assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0)
+    _, nfrag = oracle_render(pos, h, m, None, None, 0, M, sf, R, mips)
+    assert ctx.stats()["n_fragments"] == nfrag
     ctx.close()
 
 

@@ -20,7 +20,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     h = np.exp(rs.uniform(np.log(hmax * 1e-4), np.log(hmax), size=n)).astype(np.float32)
     if rs.rand() < 0.3:    # snap some footprints exactly onto class thresholds
         k = min(n, 50)
-        Pt = rs.choice([64.0, 45.254833995939045, 22.627416997969522, 11.313708498984761, 128.0, 1.0, 512.0, 64.00001, 511.99997], size=k)
+        Pt = rs.choice([64.0, 45.254833995939045, 22.627416997969522, 11.313708498984761, 128.0, 1.0, 512.0, 64.00001, 511.99997, 16.0, 15.999999, 256.0, 255.99998, 127.99999, 13.5], size=k)
         h[:k] = (Pt * scale / (2 * R)).astype(np.float32)
     m = rs.uniform(0.5, 2.0, size=n).astype(np.float32)
     q = rs.normal(size=n).astype(np.float32)

@@ -701,7 +701,7 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         return TSP_OK;
     }
     if (!strcmp(name, "huge_variant")) {
-        TSP_REQUIRE(value >= 0 && value <= 2, TSP_EINVAL, "huge_variant out of range");
+        TSP_REQUIRE(value >= 0 && value <= 3, TSP_EINVAL, "huge_variant out of range");
         ctx->huge_variant = (int)value;
         return TSP_OK;
     }

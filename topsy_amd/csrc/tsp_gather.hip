@@ -814,6 +814,221 @@ static int launch_mega(tsp_context *ctx, TileArgs ta, long long n_huge) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// kernel H4: footprints >= 64 px on the matrix cores, 16-row strips (v_mfma_f32_16x16x4_f32)
+// ---------------------------------------------------------------------------------------------
+// The same outer-product form as kernel H3 -- img[row][col] += sum_k U[row][k] V[k][col] over the texel rows k the strip
+// touches -- but on 16 x 16 pixel blocks with FOUR texel rows per instruction.  What an MFMA costs is K slots times the block
+// area, whether or not a slot's texel row meets a pixel row, so the useful fraction is 2 / (rows / t + 2) for a texel t
+// pixels tall: a 16-row block wastes half as many slots on the "+ 2" as a 32-row block, and for t >= 8 px one instruction
+// (32 cycles) covers a block.  A wave owns a 64 x 16 strip = four 16 x 16 blocks side by side: 16 accumulator registers
+// for a density render, so eight waves fit a SIMD.  Lane l = (j = l & 15, k = l >> 4):
+//   rows    lane evaluates pixel row j (its copies k = 0..3 alike) and supplies A[j][k] = gy / fy / 0 for texel row r0 + 4 m + k;
+//   columns lane l evaluates pixel column l ONCE per footprint and leaves (texel column, fx w, gx w) in a per-wave LDS
+//           table; block b then reads entry 16 b + j and supplies B[k][j] = the x-interpolated texel row r0 + 4 m + k there.
+// Barrier-free like H2 / H3 (per-wave record scans); several channels share the kernel image as in H3.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int PT4_ROWS = 72;         // 64 texel rows + clamp-to-edge copies of row 63: the k-steps read up to row 63 + 2 + 3 (+ slack)
+
+template <int MODE, int NACC, int OCC>
+__global__ __launch_bounds__(H2T, OCC) void splat_tile4_kernel(TileArgs a) {
+    constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
+    constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
+    constexpr int NB = 4;                                    // 16-column blocks per wave strip
+    constexpr int TW = 128, TH = 32;                         // tile: 2 x 2 wave strips of 64 x 16 pixels
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *PT = smem;                                        // [PT4_ROWS][PT_STRIDE] level-0 kernel image, clamp-to-edge padded
+    float4 *ct_all = reinterpret_cast<float4 *>(smem + ((PT4_ROWS * PT_STRIDE + 3) & ~3));   // per wave: 64 column entries
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lj = lane & 15, lk = lane >> 4;                // MFMA operand roles: row / column index, k index
+    const int R = a.cam.R;
+    const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
+    const int tx0 = (tile_id % a.tiles_x) * TW, ty0 = (tile_id / a.tiles_x) * TH;
+    for (int i = tid; i < PT4_ROWS * PT_STRIDE; i += H2T) {
+        const int j = min(i / PT_STRIDE, 63), x = min(i % PT_STRIDE, 63);
+        PT[i] = a.mips[j * 64 + x];
+    }
+    float4 *ct = ct_all + wv * 64;
+    const int sx = tx0 + 64 * (wv & 1), sy = ty0 + 16 * (wv >> 1);
+    const float sx0 = (float)sx, sx1 = (float)(sx + 64), sy0 = (float)sy, sy1 = (float)(sy + 16);
+    const float pyc = (sy + lj < R) ? (float)(sy + lj) + 0.5f : __builtin_inff();
+    const float pxc = (sx + lane < R) ? (float)(sx + lane) + 0.5f : __builtin_inff();
+    const int last_row = min(15, R - 1 - sy);                // last pixel row of the strip inside the image (wave-uniform)
+    constexpr int FOLD_EVERY = TSP_FOLD_EVERY;
+    f32x4 acc[NACC][NB];
+#pragma unroll
+    for (int c = 0; c < NACC; ++c)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[c][b][v] = 0.0f;
+    unsigned long long n_frag = 0;
+    int since_fold = 0;
+    const char *PTb = reinterpret_cast<const char *>(PT);
+    __syncthreads();                                         // the only workgroup barrier
+    if (sx >= R || sy >= R) return;
+
+    auto flush = [&]() {
+        double *img = a.img + ((size_t)(sy + 4 * lk) * R + (sx + lj)) * C;
+        asm volatile("" : "+v"(img));
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if (sx + 16 * b + lj < R && sy + 4 * lk + v < R) {
+                    double *d = img + ((size_t)v * R + 16 * b) * C;
+#pragma unroll
+                    for (int c = 0; c < NACC; ++c) {
+                        if (acc[c][b][v] != 0.0f) gatomic_add(d + c, acc[c][b][v]);
+                        acc[c][b][v] = 0.0f;
+                    }
+                }
+            }
+    };
+
+    const long long n_runs = (a.n_records + HDEAL - 1) / HDEAL;
+    auto fetch = [&](long long run0, float4 &g, float &gw1, float &gw2) {
+        const long long ri = ((run0 + lane / HDEAL) * a.split + sp) * HDEAL + (lane & (HDEAL - 1));
+        g = make_float4(0.f, 0.f, 0.f, 0.f); gw1 = gw2 = 0.0f;
+        if (ri < a.n_records) {
+            g = a.geom[ri];
+            gw1 = a.w[ri * NW];
+            if (NW == 2) gw2 = a.w[ri * NW + 1];
+        }
+    };
+    float4 g_next; float gw1_next, gw2_next;
+    fetch(0, g_next, gw1_next, gw2_next);
+    for (long long run0 = 0; run0 * a.split < n_runs; run0 += 64 / HDEAL) {
+        const float4 g = g_next;
+        const float gw1 = gw1_next, gw2 = gw2_next;
+        fetch(run0 + 64 / HDEAL, g_next, gw1_next, gw2_next);
+        const float g_half = 0.5f * g.z;
+        bool hit;
+        {
+            const float sdx = fmaxf(fmaxf(sx0 - g.x, g.x - sx1), 0.0f), sdy = fmaxf(fmaxf(sy0 - g.y, g.y - sy1), 0.0f);
+            hit = g.z >= a.p_lo && g.z < a.p_hi && sdx < g_half && sdy < g_half && !(a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * g.z * g.z);
+        }
+        unsigned long long hits = __ballot(hit);
+        if (hits == 0ull) continue;
+        const float g_invP = 1.0f / g.z;
+        const float g_w1 = (MODE == TSP_MODE_RGB) ? gw1 : g.w * gw1;
+        while (hits) {
+            const int src = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const float pcx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.x), src));
+            const float pcy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.y), src));
+            const float half = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_half), src));
+            const float invP = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_invP), src));
+            const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.w), src));
+            const float w1 = (NACC >= 2) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_w1), src)) : 0.0f;
+            const float w2 = (NACC >= 3) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gw2), src)) : 0.0f;
+            // ---- columns: lane l evaluates pixel column l and publishes it in the wave's table ----
+            int ncx = 0;
+            {
+                const float d = pxc - pcx;
+                const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                const float u = (d + half) * invP;
+                const float tu = __builtin_amdgcn_fmed3f(__builtin_fmaf(u, 64.0f, -0.5f), 0.0f, 63.0f);
+                const float f0 = __builtin_floorf(tu);
+                const float fr = (tu - f0) * cv;
+                const float fxw = (NACC == 1) ? fr * w0 : fr;          // density: the particle weight rides on the column factors
+                const float gxw = (NACC == 1) ? (cv - fr) * w0 : (cv - fr);
+                asm volatile("" ::: "memory");                          // (the previous footprint's table reads are done: in-order LDS)
+                ct[lane] = make_float4(__int_as_float(((int)f0) * 4), fxw, gxw, 0.0f);
+                asm volatile("" ::: "memory");
+                if (a.count_frag) ncx = __popcll(__ballot(cv != 0.0f));
+            }
+            // ---- rows (A operand): lane (j, k) evaluates pixel row j; canonical texel coordinate (tsp_math.h) ----
+            float fy, gy;
+            int rel, r0, nsteps;
+            {
+                const float d = pyc - pcy;
+                const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                const float v = (d + half) * invP;
+                const float tv = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, 64.0f, -0.5f), 0.0f, 63.0f);
+                const float f0 = __builtin_floorf(tv);
+                fy = (tv - f0) * cv;
+                gy = cv - fy;
+                const int r = (int)f0;
+                r0 = __builtin_amdgcn_readlane(r, 0);                 // texel row of the strip's first pixel row
+                rel = r - r0;
+                const int kmax = __builtin_amdgcn_readlane(rel, last_row);   // texel rows are monotone down the strip
+                nsteps = (kmax + 5) >> 2;                             // texel rows r0 .. r0 + kmax + 1, four per MFMA
+                if (a.count_frag) {
+                    const unsigned long long rows = __ballot(cv != 0.0f && lk == 0);
+                    if (lane == 0) n_frag += (unsigned long long)(ncx * __popcll(rows));
+                }
+            }
+            float4 col[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) col[b] = ct[16 * b + lj];
+            int rowoff = (r0 + lk) * (PT_STRIDE * 4);   // this lane's texel row of the current k-step (bytes)
+            int kk = lk;
+            if constexpr (NACC == 1) {
+                for (int m = 0; m < nsteps; ++m) {
+                    const float A = (rel == kk) ? gy : ((rel + 1 == kk) ? fy : 0.0f);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const float *t = reinterpret_cast<const float *>(PTb + rowoff + __float_as_int(col[b].x));
+                        const float L = __builtin_fmaf(t[1], col[b].y, t[0] * col[b].z);
+                        acc[0][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, L, acc[0][b], 0, 0, 0);
+                    }
+                    kk += 4;
+                    rowoff += 4 * PT_STRIDE * 4;
+                }
+            } else {
+                f32x4 kimg[NB];
+                for (int m = 0; m < nsteps; ++m) {
+                    const float A = (rel == kk) ? gy : ((rel + 1 == kk) ? fy : 0.0f);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const float *t = reinterpret_cast<const float *>(PTb + rowoff + __float_as_int(col[b].x));
+                        const float L = __builtin_fmaf(t[1], col[b].y, t[0] * col[b].z);
+                        if (m == 0) {
+                            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                            kimg[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, L, zero, 0, 0, 0);
+                        } else {
+                            kimg[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(A, L, kimg[b], 0, 0, 0);
+                        }
+                    }
+                    kk += 4;
+                    rowoff += 4 * PT_STRIDE * 4;
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        acc[0][b][v] = __builtin_fmaf(kimg[b][v], w0, acc[0][b][v]);
+                        acc[NACC >= 2 ? 1 : 0][b][v] = __builtin_fmaf(kimg[b][v], w1, acc[NACC >= 2 ? 1 : 0][b][v]);
+                        if (NACC >= 3) acc[NACC - 1][b][v] = __builtin_fmaf(kimg[b][v], w2, acc[NACC - 1][b][v]);
+                    }
+            }
+            if (++since_fold == FOLD_EVERY) { since_fold = 0; flush(); }
+        }
+    }
+    flush();
+    if (a.count_frag) {
+        for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
+        if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+    }
+}
+
+template <int MODE, int NACC, int OCC>
+static int launch_tile4(tsp_context *ctx, TileArgs ta, long long n_records) {
+    const size_t smem = (size_t)((PT4_ROWS * PT_STRIDE + 3) & ~3) * sizeof(float) + (H2T / 64) * 64 * sizeof(float4);
+    const int htiles_x = (ctx->R + 127) / 128, htiles_y = (ctx->R + 31) / 32;
+    const int htiles = htiles_x * htiles_y;
+    const long long batches = (n_records + 63) / 64;
+    int split = ctx->huge_split;
+    if (split <= 0) split = std::max(1, (ctx->cu_count * 128 + htiles - 1) / htiles);
+    split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
+    ta.split = split;
+    ta.tiles_x = htiles_x;
+    hipLaunchKernelGGL((splat_tile4_kernel<MODE, NACC, OCC>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
+    TSP_HIP(hipGetLastError());
+    return TSP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: which kernel takes which class
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
@@ -832,6 +1047,9 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
             if (MODE == TSP_MODE_RGB) rc = launch_huge<MODE, 3, 4>(ctx, ta, smem_h, n_huge);
             else if (second_channel) rc = launch_huge<MODE, 2, 4>(ctx, ta, smem_h, n_huge);
             else rc = launch_huge<MODE, 1, 4>(ctx, ta, smem_h, n_huge);   // 4x8 px/lane measured slower (spills, larger tiles)
+        } else if (ctx->huge_variant == 3) {    // kernel H4 (matrix cores, 16-row strips): 64 px <= P < p_mega
+            if (second_channel) rc = launch_tile4<MODE, 2, 5>(ctx, ta, n_huge);
+            else rc = launch_tile4<MODE, 1, 6>(ctx, ta, n_huge);
         } else {                                // kernel H2 (row-uniform gather): 64 px <= P < p_mega
             if (second_channel) rc = launch_huge2<MODE, 2, 1, 16, 4>(ctx, ta, n_huge);      // 5-6 waves/SIMD spill: 21 / 31 vs 16 ms
             else if (ctx->huge_variant == 2) rc = launch_huge2<MODE, 1, 1, 32, 4>(ctx, ta, n_huge);
