@@ -62,6 +62,9 @@ struct Workspace {     // per-context scratch of the three-class pipeline (grown
     long long *seg_offset = nullptr;    // per chunk: first record of its contiguous run
     float4 *seg_bbox = nullptr;         // per chunk: pixel bbox of its mid footprints (x0, y0, x1, y1)
     int64_t seg_capacity = 0;
+    int *band_count = nullptr;          // per image band (<= 32 bands of whole tile rows): chunks whose mid footprints reach it
+    int64_t band_capacity = 0;          // slots per band
+    int *band_list = nullptr;           // [32][seg_capacity] chunk indices, appended by kernel S in arrival order
     int64_t *range_prefix = nullptr;    // device copy of the ranges of the current call
     int64_t range_capacity = 0;
     int *count_diff = nullptr;          // rgb: (R+1)^2 corner-difference image of the huge footprints' pixel rectangles

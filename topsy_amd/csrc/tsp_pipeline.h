@@ -35,6 +35,8 @@ constexpr int MSTR = 72;             // LDS row stride (doubles) of the mid tile
 // edge of kernel S's LDS window by the number of channels it holds (1: density, 2: weighted / depth, 4: rgb)
 template <int WC> struct WinSize { static constexpr int value = (WC == 1) ? TSP_WIN1 : (WC == 2 ? TSP_WIN2 : TSP_WIN4); };
 
+constexpr int NBANDS = 32;           // image bands of the chunk lists kernel S bins for kernel M (each a whole number of 32-row tile rows)
+
 enum { CLS_NONE = 0, CLS_SMALL = 1, CLS_MID = 2, CLS_HUGE = 3, CLS_MEGA = 4 };
 
 // the render target is accumulated in float64 (global_atomic_add_f64) and rounded to float32 once per
@@ -58,6 +60,7 @@ struct TileArgs {
     const float4 *geom; const float *w;
     long long n_records;
     const int *seg_count; const long long *seg_offset; const float4 *seg_bbox; int n_chunks;
+    const int *band_count; const int *band_list; long long band_cap; int band_h;   // kernel M: the chunks to look at, per image band
     Camera cam;
     const float *mips;
     double *img;

@@ -96,6 +96,7 @@ struct StreamArgs {
     float4 *mid_geom;  float *mid_w;   int64_t mid_capacity;
     float4 *huge_geom; float *huge_w;  int64_t huge_capacity;
     int *seg_count; long long *seg_offset; float4 *seg_bbox;
+    int *band_count; int *band_list; long long band_cap; int band_h;     // per image band: the chunks that have mid footprints there
     Counters *cnt;
     float p_small;
     float p_mega;              // footprints at least this wide are appended from the END of the huge list (kernel H3's share)
@@ -321,6 +322,18 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         }
         __syncthreads();
         const long long mid_base = s_base[0], huge_base = s_base[1];
+        if (tid == SBLOCK - 1 && mid_total) {
+            // Kernel M's workgroups look only at the chunks of their own image band: one or two appends per chunk here against
+            // a scan of every chunk header by every tile there.  Done by the LAST thread after the barrier, off the
+            // workgroup's critical path (the returning atomic costs a round trip to L2 that only this wave waits for;
+            // s_mbb is not rewritten before the next chunk's first barrier).  Aggregating the appends per workgroup (one
+            // atomic per workgroup and band) measured slower: +0.15 ms on this kernel for its two extra barriers.
+            unsigned lo = s_mbb[0][0], hi = s_mbb[0][1];
+#pragma unroll
+            for (int w = 1; w < SWAVES; ++w) { lo = pk_min_u16(lo, s_mbb[w][0]); hi = pk_max_u16(hi, s_mbb[w][1]); }
+            const int b0 = (int)(lo >> 16) / a.band_h, b1 = (int)(hi >> 16) / a.band_h;
+            for (int b = b0; b <= b1; ++b) a.band_list[(long long)b * a.band_cap + atomicAdd(&a.band_count[b], 1)] = c;
+        }
         const int my_mid = my_counts & 0xffff, my_huge = my_counts >> 16;
         const int mid_before = counts_before & 0xffff, huge_before = counts_before >> 16;
         const int mid_incl = counts_incl & 0xffff, huge_incl = counts_incl >> 16;
@@ -527,19 +540,22 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
     unsigned long long n_frag = 0;
     bool touched = false;
 
-    // segment headers are examined 256 at a time (one per lane).  Consecutive segments are spatial
-    // neighbours, so they are dealt to the `split` workgroups of this tile with stride `split`:
-    // every workgroup sees a uniform sample of the tile's segments (an even share of its work)
-    for (int sbase = 0; sbase * a.split < a.n_chunks; sbase += MT) {
-        const int seg = (sbase + tid) * a.split + sp;
+    // The chunks whose mid footprints reach this tile's image band were listed by kernel S (band_list); their headers are
+    // examined 512 at a time (one per lane).  They are dealt to the `split` workgroups of this tile with stride `split`:
+    // every workgroup sees an even sample of the band's chunks (an even share of the tile's work)
+    const int band = ty0 / a.band_h;
+    const int n_list = a.band_count[band];
+    const int *blist = a.band_list + (long long)band * a.band_cap;
+    for (int sbase = 0; sbase * a.split < n_list; sbase += MT) {
+        const int li = (sbase + tid) * a.split + sp;
+        int seg = 0;
         bool shit = false;
         int scnt = 0;
-        if (seg < a.n_chunks) {
+        if (li < n_list) {
+            seg = blist[li];
             scnt = a.seg_count[seg];
-            if (scnt > 0) {
-                const float4 bb = a.seg_bbox[seg];
-                shit = bb.x < fx1 && bb.z > fx0 && bb.y < fy1 && bb.w > fy0;
-            }
+            const float4 bb = a.seg_bbox[seg];
+            shit = bb.x < fx1 && bb.z > fx0 && bb.y < fy1 && bb.w > fy0;
         }
         const unsigned long long smask = __ballot(shit);
         const int sbefore = __popcll(smask & ((1ull << lane) - 1ull));
@@ -797,6 +813,18 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         TSP_HIP(hipMalloc((void **)&ws.seg_offset, ws.seg_capacity * sizeof(long long)));
         TSP_HIP(hipMalloc((void **)&ws.seg_bbox, ws.seg_capacity * sizeof(float4)));
     }
+    {   // per band: at most every chunk once
+        const int64_t need = (int64_t)n_chunks + 64;
+        if (ws.band_capacity < need) {
+            if (ws.band_list) TSP_HIP(hipFree(ws.band_list));
+            ws.band_list = nullptr;
+            ws.band_capacity = need + need / 4;
+            TSP_HIP(hipMalloc((void **)&ws.band_list, (size_t)NBANDS * ws.band_capacity * sizeof(int)));
+        }
+    }
+    if (!ws.band_count) TSP_HIP(hipMalloc((void **)&ws.band_count, NBANDS * sizeof(int)));
+    // image bands of kernel M's chunk lists: at most NBANDS, each a whole number of 32-row tile rows
+    const int band_h = (((ctx->R + NBANDS - 1) / NBANDS + 31) / 32) * 32;
     // record lists: start modest, grow to the exact need when a frame overflows (rare)
     int rc;
     if (ws.mid_capacity == 0) {
@@ -863,6 +891,8 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         sa.mid_geom = (float4 *)ws.mid_geom; sa.mid_w = (float *)ws.mid_w; sa.mid_capacity = ws.mid_capacity;
         sa.huge_geom = (float4 *)ws.huge_geom; sa.huge_w = (float *)ws.huge_w; sa.huge_capacity = ws.huge_capacity;
         sa.seg_count = ws.seg_count; sa.seg_offset = ws.seg_offset; sa.seg_bbox = ws.seg_bbox;
+        sa.band_count = ws.band_count; sa.band_list = ws.band_list; sa.band_cap = ws.band_capacity; sa.band_h = band_h;
+        TSP_HIP(hipMemsetAsync(ws.band_count, 0, NBANDS * sizeof(int), st));
         sa.cnt = ctx->counters; sa.p_small = ctx->p_small; {
             const float pm = (MODE == TSP_MODE_RGB) ? (ctx->rgb_mega_variant > 0 ? ctx->p_mega_rgb : 0.0f) : (second_channel ? ctx->p_mega2 : ctx->p_mega);
             sa.p_mega = (ctx->huge_variant != 0 && pm > 0.0f) ? pm : __builtin_inff();
@@ -902,6 +932,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     }
     TileArgs ta;
     ta.seg_count = ws.seg_count; ta.seg_offset = ws.seg_offset; ta.seg_bbox = ws.seg_bbox; ta.n_chunks = n_chunks;
+    ta.band_count = ws.band_count; ta.band_list = ws.band_list; ta.band_cap = ws.band_capacity; ta.band_h = band_h;
     ta.cam = cam; ta.mips = ctx->mips; ta.img = ctx->image64; ta.cnt = ctx->counters; ta.tiles_x = tiles_x;
     ta.count_frag = ctx->count_fragments ? 1 : 0;
     // corner culling is exact for the value channels; the rgb counter channel (which also counts zero-valued
