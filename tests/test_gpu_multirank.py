@@ -135,3 +135,38 @@ def test_visualizer_two_gpus_rccl():
     assert np.allclose(got_img[..., 0], want_img[..., 0], rtol=1e-5, atol=0)
     assert (np.abs(got_rgba.astype(int) - want_rgba.astype(int)) <= 1).all()
     two.close()
+
+
+def test_rgb_and_depth_on_several_contexts_of_one_device():
+    """rgb mode (band magnitudes contracted on every shard's device), the depth pass and the periodic tiling through the
+    multi-context driver equal the one-context results."""
+    import topsy_amd
+    from topsy_amd import loader, visualizer
+    from topsy_amd.drawreason import DrawReason
+    rs = np.random.RandomState(4)
+    n, R = 60000, 128
+    pos = (rs.normal(size=(n, 3)) * 20.0).astype(np.float32)
+    h = np.exp(rs.uniform(np.log(0.05), np.log(8.0), n)).astype(np.float32)
+    mags = {b: rs.uniform(2.0, 14.0, n) for b in "IVU"}
+    imgs, depths = [], []
+    for dev in (None, [0, 0]):
+        v = visualizer.Visualizer(data_loader_class=loader.ArrayDataLoader,
+                                  data_loader_kwargs=dict(pos=pos, smooth=h, mass=np.ones(n, np.float32), band_magnitudes=mags),
+                                  render_resolution=R, render_mode="rgb", device_ids=dev)
+        v.scale = 80.0
+        imgs.append(v._sph.get_image().copy())
+        depths.append(v.get_depth_image().copy())
+        v.close()
+    assert np.allclose(imgs[0][..., :3], imgs[1][..., :3], rtol=1e-5, atol=0)
+    assert np.array_equal(imgs[0][..., 3], imgs[1][..., 3])
+    fin = np.isfinite(depths[0]) & np.isfinite(depths[1])
+    assert fin.sum() > 1000 and np.allclose(depths[0][fin], depths[1][fin], rtol=1e-4, atol=1e-3)
+    # periodic tiling on the first context after the reduce
+    outs = []
+    for dev in (None, [0, 0]):
+        v = topsy_amd.test(2000, render_resolution=R, periodic_tiling=True, device_ids=dev)
+        v.scale = 150.0
+        v.render_sph(DrawReason.EXPORT)
+        outs.append(v.get_sph_image().copy())
+        v.close()
+    assert np.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-30)
