@@ -649,7 +649,7 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                                 if (MODE == TSP_MODE_RGB) {     // the counter channel is summed by add_rect_counts()
                                     latomic_add(d, kv * w0); latomic_add(d + MTILE_H * MSTR, kv * w1);
                                     latomic_add(d + 2 * MTILE_H * MSTR, kv * w2);
-                                } else {
+                                } else {      // (skipping the exactly-zero corner texels lane by lane measured slower: 5.5 -> 6.0 ms)
                                     const float val = kv * w0;
                                     latomic_add(d, val);
                                     if (WC > 1) latomic_add(d + MTILE_H * MSTR, val * w1);
