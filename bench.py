@@ -80,6 +80,8 @@ def profile_entry(prof, kernel, mode):
     template arguments): exactly one key may match, else None -- never 'the last one that contains the name'."""
     tmpl_mode = 2 if mode == "rgb" else 0
     first = {"density": "1", "weighted": "2", "rgb": None}[mode]
+    if kernel == "splat_mega64_kernel":      # <MODE, waves per SIMD>: density only
+        first = None
     hits = []
     for k, v in prof.get("per_kernel", {}).items():
         name, _, args = k.partition("<")
@@ -208,7 +210,7 @@ def main():
     else:
         dom = max(parts, key=parts.get)
         dom_ms = parts[dom]
-        dom = {"stream": "splat_stream_kernel", "mid": "splat_mid_kernel", "mega": "splat_mega_kernel",
+        dom = {"stream": "splat_stream_kernel", "mid": "splat_mid_kernel", "mega": "splat_mega64_kernel",
                "huge": "splat_huge_kernel" if args.mode == "rgb" else "splat_huge2_kernel"}[dom]
     bytes_per_launch = B_ALG[args.mode] * n_per
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -222,15 +224,18 @@ def main():
     # MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); null when no profile matches this workload
     traffic = traffic_kernel = None
     mfma_per_launch = None      # v_mfma_f32_* instructions of kernel H3 per launch (PMC SQ_INSTS_MFMA)
+    mega_kernel = "splat_mega_kernel"
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "latest_bench_counters.json")))
         if prof.get("bench_line", {}).get("config", {}).get("workload") == workload_name:
             traffic_kernel, v = profile_entry(prof, dom, args.mode)
             if v is not None:
                 traffic = (v.get("hbm_read_bytes_corrected", 0.0) + v.get("hbm_write_bytes", 0.0)) / 1e9
-            _, v = profile_entry(prof, "splat_mega_kernel", args.mode)
-            if v is not None and v.get("SQ_INSTS_MFMA"):
-                mfma_per_launch = v["SQ_INSTS_MFMA"]
+            for mega_name in ("splat_mega64_kernel", "splat_mega_kernel"):      # 64 x 64 or 64 x 32 strips, whichever ran
+                _, v = profile_entry(prof, mega_name, args.mode)
+                if v is not None and v.get("SQ_INSTS_MFMA"):
+                    mfma_per_launch, mega_kernel = v["SQ_INSTS_MFMA"], mega_name
+                    break
     except Exception:
         pass
     result = {
@@ -256,7 +261,7 @@ def main():
     if mfma_per_launch and means["mega"] > 0:
         # the matrix-core kernel against ITS roofline: instruction count from the committed PMC pass, duration live
         tflops = mfma_per_launch * 2 * 32 * 32 * 2 / (means["mega"] * 1e-3) / 1e12
-        result["roofline_mega"] = {"bound": "mfma", "kernel": "splat_mega_kernel", "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS,
+        result["roofline_mega"] = {"bound": "mfma", "kernel": mega_kernel, "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS, "kernel_ms": means["mega"],
                                    "mfma_instructions_per_launch": mfma_per_launch}
     extras = world == 1 and not args.generic and not args.headline_only and args.h_cap_px <= 0

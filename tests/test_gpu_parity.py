@@ -528,6 +528,12 @@ def test_gather_kernels_fold_their_accumulators(native, mips):
     assert ctx.stats()["n_mega"] == n // 2 and ctx.stats()["n_huge"] == n
     want, _ = oracle_render(pos, h, m, None, None, 0, M, sf, R, mips)
     assert np.allclose(got[..., 0], want[..., 0], rtol=1e-5, atol=0)
+    for variant in (1, 2, 3):                  # kernel H3 on 64 x 32 strips, on 64 x 64 strips at 4 / 3 waves per SIMD
+        ctx.set_option("mega_variant", variant)
+        ctx.render(M, sf)
+        assert ctx.stats()["n_mega"] == n // 2
+        assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0), variant
+    ctx.set_option("mega_variant", 0)
     ctx.set_option("p_mega_px", 0)             # everything >= 64 px through kernel H2
     ctx.render(M, sf)
     assert ctx.stats()["n_mega"] == 0

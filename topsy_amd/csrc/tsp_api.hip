@@ -695,6 +695,11 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         (name[6] == '2' ? ctx->p_mega2 : (name[6] == '_' && name[7] == 'r' ? ctx->p_mega_rgb : ctx->p_mega)) = (float)value;
         return TSP_OK;
     }
+    if (!strcmp(name, "mega_variant")) {
+        TSP_REQUIRE(value >= 0 && value <= 3, TSP_EINVAL, "mega_variant out of range");
+        ctx->mega_variant = (int)value;
+        return TSP_OK;
+    }
     if (!strcmp(name, "rgb_mega_variant")) {
         TSP_REQUIRE(value >= 0 && value <= 3, TSP_EINVAL, "rgb_mega_variant out of range");
         ctx->rgb_mega_variant = (int)value;

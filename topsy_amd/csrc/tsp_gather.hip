@@ -797,6 +797,170 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
     }
 }
 
+// Density-only variant of kernel H3 with 64 x 64 wave strips (two row blocks of two column blocks): the column factors and
+// the footprint's parameters are prepared once for 4096 pixels instead of 2048 (experiment, `mega_variant` = 1).
+template <int MODE, int OCC>
+__global__ __launch_bounds__(H2T, OCC) void splat_mega64_kernel(TileArgs a) {
+    constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
+    constexpr int NB = 2, NR = 2;
+    constexpr int TW = 128, TH = 128;                      // tile: 2 x 2 wave strips of 64 x 64 pixels
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *PT = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int R = a.cam.R;
+    const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
+    const int tx0 = (tile_id % a.tiles_x) * TW, ty0 = (tile_id / a.tiles_x) * TH;
+    for (int i = tid; i < PT_ROWS * PT_STRIDE; i += H2T) {
+        const int j = min(i / PT_STRIDE, 63), x = min(i % PT_STRIDE, 63);
+        PT[i] = a.mips[j * 64 + x];
+    }
+    const int sx = tx0 + 64 * (wv & 1), sy = ty0 + 64 * (wv >> 1);
+    const float sx0 = (float)sx, sx1 = (float)(sx + 64), sy0 = (float)sy, sy1 = (float)(sy + 64);
+    float pyc[NR], pxc[NB];
+    int last_row[NR];
+#pragma unroll
+    for (int rb = 0; rb < NR; ++rb) {
+        pyc[rb] = (sy + 32 * rb + li < R) ? (float)(sy + 32 * rb + li) + 0.5f : __builtin_inff();
+        last_row[rb] = min(31, R - 1 - (sy + 32 * rb));    // < 0: the row block lies outside the image
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) pxc[b] = (sx + 32 * b + li < R) ? (float)(sx + 32 * b + li) + 0.5f : __builtin_inff();
+    constexpr int FOLD_EVERY = TSP_FOLD_EVERY;
+    f32x16 acc[NR][NB];
+#pragma unroll
+    for (int rb = 0; rb < NR; ++rb)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[rb][b][v] = 0.0f;
+    unsigned long long n_frag = 0;
+    int since_fold = 0;
+    const char *PTb = reinterpret_cast<const char *>(PT);
+    __syncthreads();
+    if (sx >= R || sy >= R) return;
+
+    auto flush = [&]() {
+#pragma unroll
+        for (int rb = 0; rb < NR; ++rb) {
+            double *img = a.img + ((size_t)(sy + 32 * rb + 4 * kh) * R + (sx + li)) * C;
+            asm volatile("" : "+v"(img));
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = (v >> 2) * 8 + (v & 3);
+                    if (sx + 32 * b + li < R && sy + 32 * rb + 4 * kh + row < R) {
+                        double *d = img + ((size_t)row * R + 32 * b) * C;
+                        if (acc[rb][b][v] != 0.0f) gatomic_add(d, acc[rb][b][v]);
+                        acc[rb][b][v] = 0.0f;
+                    }
+                }
+        }
+    };
+
+    const long long n_runs = (a.n_records + HDEAL - 1) / HDEAL;
+    auto fetch = [&](long long run0, float4 &g) {
+        const long long ri = ((run0 + lane / HDEAL) * a.split + sp) * HDEAL + (lane & (HDEAL - 1));
+        g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ri < a.n_records) g = a.geom[ri];
+    };
+    float4 g_next;
+    fetch(0, g_next);
+    for (long long run0 = 0; run0 * a.split < n_runs; run0 += 64 / HDEAL) {
+        const float4 g = g_next;
+        fetch(run0 + 64 / HDEAL, g_next);
+        const float g_half = 0.5f * g.z;
+        bool hit;
+        {
+            const float sdx = fmaxf(fmaxf(sx0 - g.x, g.x - sx1), 0.0f), sdy = fmaxf(fmaxf(sy0 - g.y, g.y - sy1), 0.0f);
+            hit = g.z >= a.p_lo && sdx < g_half && sdy < g_half && !(a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * g.z * g.z);
+        }
+        unsigned long long hits = __ballot(hit);
+        if (hits == 0ull) continue;
+        const float g_invP = 1.0f / g.z;
+        while (hits) {
+            const int src = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const float pcx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.x), src));
+            const float pcy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.y), src));
+            const float half = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_half), src));
+            const float invP = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_invP), src));
+            const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.w), src));
+            // ---- columns (B operand), shared by the row blocks ----
+            int caddr[NB];
+            float fxs[NB], gxs[NB];
+            int ncx = 0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float d = pxc[b] - pcx;
+                const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                const float u = (d + half) * invP;
+                const float tu = __builtin_amdgcn_fmed3f(__builtin_fmaf(u, 64.0f, -0.5f), 0.0f, 63.0f);
+                const float f0 = __builtin_floorf(tu);
+                const float fr = (tu - f0) * cv;
+                caddr[b] = ((int)f0) * 4;
+                fxs[b] = fr * w0;
+                gxs[b] = (cv - fr) * w0;
+                if (a.count_frag) ncx += (cv != 0.0f) ? 1 : 0;
+            }
+#pragma unroll
+            for (int rb = 0; rb < NR; ++rb) {
+                if (last_row[rb] < 0) continue;
+                const float d = pyc[rb] - pcy;
+                const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                const unsigned long long rows = __ballot(cv != 0.0f && kh == 0);
+                if (rows == 0ull) continue;                           // the footprint misses this row block
+                const float v = (d + half) * invP;
+                const float tv = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, 64.0f, -0.5f), 0.0f, 63.0f);
+                const float f0 = __builtin_floorf(tv);
+                const float fy = (tv - f0) * cv, gy = cv - fy;
+                const int r = (int)f0;
+                const int r0 = __builtin_amdgcn_readlane(r, 0);
+                const int rel = r - r0;
+                const int kmax = __builtin_amdgcn_readlane(rel, last_row[rb]);
+                const int nsteps = (kmax + 3) >> 1;
+                if (a.count_frag && kh == 0) n_frag += (unsigned long long)(ncx * __popcll(rows));
+                int rowoff = (r0 + kh) * (PT_STRIDE * 4);
+                int kk = kh;
+                for (int m = 0; m < nsteps; ++m) {
+                    const float A = (rel == kk) ? gy : ((rel + 1 == kk) ? fy : 0.0f);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const float *t = reinterpret_cast<const float *>(PTb + rowoff + caddr[b]);
+                        const float L = __builtin_fmaf(t[1], fxs[b], t[0] * gxs[b]);
+                        acc[rb][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, L, acc[rb][b], 0, 0, 0);
+                    }
+                    kk += 2;
+                    rowoff += 2 * PT_STRIDE * 4;
+                }
+            }
+            if (++since_fold == FOLD_EVERY) { since_fold = 0; flush(); }
+        }
+    }
+    flush();
+    if (a.count_frag) {
+        for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
+        if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+    }
+}
+
+template <int MODE, int OCC>
+static int launch_mega64(tsp_context *ctx, TileArgs ta, long long n_huge) {
+    const size_t smem = (size_t)((PT_ROWS * PT_STRIDE + 3) & ~3) * sizeof(float);
+    const int htiles_x = (ctx->R + 127) / 128, htiles_y = (ctx->R + 127) / 128;
+    const int htiles = htiles_x * htiles_y;
+    const long long batches = (n_huge + 63) / 64;
+    int split = ctx->mega_split;
+    if (split <= 0) split = std::max(1, (ctx->cu_count * 32 + htiles - 1) / htiles);      // 128 at 1024^2 (96 ... 160 alike; 256: +10 %)
+    split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
+    ta.split = split;
+    ta.tiles_x = htiles_x;
+    hipLaunchKernelGGL((splat_mega64_kernel<MODE, OCC>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
+    TSP_HIP(hipGetLastError());
+    return TSP_OK;
+}
+
 template <int MODE, int NACC, int NB, int OCC>
 static int launch_mega(tsp_context *ctx, TileArgs ta, long long n_huge) {
     const size_t smem = (size_t)((PT_ROWS * PT_STRIDE + 3) & ~3) * sizeof(float);
@@ -1066,6 +1230,10 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
             else if (ctx->rgb_mega_variant == 2) rc = launch_mega<MODE, 3, 2, 3>(ctx, ta, n_mega);
             else rc = launch_mega<MODE, 3, 1, 3>(ctx, ta, n_mega);
         } else if (second_channel) rc = launch_mega<MODE, 2, 2, 3>(ctx, ta, n_mega);      // 64 accumulator + 32 scratch registers: 3 waves/SIMD (4 would spill)
+        // density: 64 x 64 strips (column factors and parameters prepared once per 4096 pixels) once there are enough records to
+        // keep their fewer, longer workgroups busy: 1.25e8 particles 6.3 -> 6.0 ms, 1e9: 18.2 -> 17.3 ms, but 1e7: 2.1 -> 2.25 ms
+        else if (ctx->mega_variant == 2 || (ctx->mega_variant == 0 && n_mega >= 40000)) rc = launch_mega64<MODE, 4>(ctx, ta, n_mega);
+        else if (ctx->mega_variant == 3) rc = launch_mega64<MODE, 3>(ctx, ta, n_mega);
         else rc = launch_mega<MODE, 1, 2, 4>(ctx, ta, n_mega);   // 4 column blocks per strip and 5-6 waves/SIMD measured no faster
         if (rc) return rc;
     }

@@ -114,6 +114,7 @@ struct tsp_context {
     float p_mega = 512.0f;            // density renders: footprints at least this wide go to kernel H3 (matrix cores); 0 = all to H2
     float p_mega2 = 256.0f;           // the same for two-channel renders (weighted, depth): their H2 pays 5 instead of 2 FMAs per pixel row
     float p_mega_rgb = 128.0f;        // ... and for rgb (kernel H below, kernel H3 with three accumulator sets above)
+    int mega_variant = 0;             // density: 0 = auto, 1 = kernel H3 on 64 x 32 strips, 2 / 3 = on 64 x 64 strips at 4 / 3 waves per SIMD
     int rgb_mega_variant = 3;         // rgb: 0 = every footprint >= 64 px on kernel H; 1-3: those >= p_mega on kernel H3 with three accumulator sets
     int huge_variant = 1;             // 0: kernel H (per-pixel gather, A/B only), 1: kernels H2 (64x16 strips) + H3, 2: H2 with 64x32 strips (density)
     int mid_split = 128, huge_split = 0, mega_split = 0;  // workgroups per image tile (0 = auto)
