@@ -1216,7 +1216,7 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
             else rc = launch_tile4<MODE, 1, 6>(ctx, ta, n_huge);
         } else {                                // kernel H2 (row-uniform gather): 64 px <= P < p_mega
             if (second_channel) rc = launch_huge2<MODE, 2, 1, 16, 4>(ctx, ta, n_huge);      // 5-6 waves/SIMD spill: 21 / 31 vs 16 ms
-            else if (ctx->huge_variant == 2) rc = launch_huge2<MODE, 1, 1, 32, 4>(ctx, ta, n_huge);
+            else if (ctx->huge_variant == 2) rc = launch_huge2<MODE, 1, 1, 32, 4>(ctx, ta, n_huge);     // (round 3: 12.0 vs 10.5 ms; at 5 waves/SIMD 12.7)
             else rc = launch_huge2<MODE, 1, 1, 16, 6>(ctx, ta, n_huge);   // 64x16 strips at 6 waves/SIMD: 17.3 ms against 18.6 for 64x32 at 4
         }
         if (rc) return rc;
