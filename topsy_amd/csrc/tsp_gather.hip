@@ -585,7 +585,11 @@ static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
     int split = ctx->huge_split;
     // many short workgroups: a wave lives ~1 ms at split 64 and the tail of the launch (tiles differ 10x in work)
     // cost 2.5 ms of 21; measured 64 -> 128: 21.9 -> 19.5 ms, 256: 19.2 ms, 512: 22.5 ms
-    if (split <= 0) split = std::max(1, (ctx->cu_count * 128 + htiles - 1) / htiles);
+    if (split <= 0) {
+        split = std::max(1, (ctx->cu_count * 128 + htiles - 1) / htiles);
+        // a small render block: fewer, longer workgroups (each loads the kernel image) in proportion below 2^16 records
+        if (n_huge < (1ll << 16)) split = std::max(32, (int)((long long)split * n_huge >> 16));
+    }
     split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
     ta.split = split;
     ta.tiles_x = htiles_x;

@@ -884,8 +884,11 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         sa.p = parts;
         sa.ranges = ws.range_prefix; sa.n_ranges = n_ranges; sa.n_chunks = n_chunks;
         const int max_blocks = ctx->cu_count * ctx->stream_blocks_per_cu;
-        // at least 8 consecutive chunks per workgroup: amortises the window set-up and keeps the window following the chunks
-        sa.chunks_per_block = std::max(8, (n_chunks + max_blocks - 1) / max_blocks);
+        // at least 8 consecutive chunks per workgroup (amortises the window set-up and keeps the window following the chunks),
+        // fewer only for a small render block that would otherwise leave most CUs idle (an interactive first block of 1e5
+        // particles is 196 chunks)
+        const int min_cpb = std::max(1, std::min(8, n_chunks / (ctx->cu_count * 2)));
+        sa.chunks_per_block = std::max(min_cpb, (n_chunks + max_blocks - 1) / max_blocks);
         const int grid_s = (n_chunks + sa.chunks_per_block - 1) / sa.chunks_per_block;
         sa.cam = cam; sa.mips = ctx->mips; sa.img = ctx->image64;
         sa.mid_geom = (float4 *)ws.mid_geom; sa.mid_w = (float *)ws.mid_w; sa.mid_capacity = ws.mid_capacity;
@@ -949,6 +952,9 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     if (hc.n_mid > 0) {
         ta.geom = (const float4 *)ws.mid_geom; ta.w = (const float *)ws.mid_w; ta.n_records = (long long)hc.n_mid;
         ta.split = std::max(1, ctx->mid_split * mth / 32);     // the same number of workgroups per image area for both tile heights
+        // a small render block (an interactive frame's first 1e5 particles leave ~3e4 records) does not need 65 536
+        // workgroups that each load the LUT: fewer splits in proportion below 2^18 records
+        if ((long long)hc.n_mid < (1ll << 18)) ta.split = std::max(4, (int)((long long)ta.split * (long long)hc.n_mid >> 18));
         const dim3 grid_m(tiles_x * mtiles_y * ta.split);
         if (WCr == 1 && quad) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1, true>), grid_m, dim3(MT), smem_m, st_mid, ta);
         else if (WCr == 1) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1, false>), grid_m, dim3(MT), smem_m, st_mid, ta);
