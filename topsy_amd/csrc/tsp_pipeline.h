@@ -42,7 +42,11 @@ enum { CLS_NONE = 0, CLS_SMALL = 1, CLS_MID = 2, CLS_HUGE = 3, CLS_MEGA = 4 };
 // the render target is accumulated in float64 (global_atomic_add_f64) and rounded to float32 once per
 // tsp_render call, so cross-workgroup summation adds no float32 noise however many flushes hit a pixel
 __device__ __forceinline__ void gatomic_add(double *addr, double v) {
+#ifdef TSP_DEBUG_NO_FLUSH      // measurement aid: what the float64 flush atomics cost (the image is then empty)
+    if (v == 123.456) *addr = v;
+#else
     __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 __device__ __forceinline__ void latomic_add(double *addr, float v) {
     __hip_atomic_fetch_add(addr, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
