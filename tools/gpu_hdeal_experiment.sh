@@ -1,5 +1,7 @@
 #!/bin/bash
-# round-3 GPU batch A: the whole -m gpu suite, the bench + profiles, and the HDEAL 4-vs-16 FETCH_SIZE experiment for kernel H2
+# The HDEAL 4-vs-16 FETCH_SIZE experiment for kernel H2: build the variant first with
+#   tools/build_variant.sh hdeal4 -DTSP_HDEAL=4
+# then run this on the GPU box (it also runs the -m gpu suite and the bench + profiles)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r3a
 ( time python3 -m pytest tests -m gpu -x -q ) > gpurun_out/r3a/pytest.log 2>&1
