@@ -210,7 +210,8 @@ def main():
     else:
         dom = max(parts, key=parts.get)
         dom_ms = parts[dom]
-        dom = {"stream": "splat_stream_kernel", "mid": "splat_mid_kernel", "mega": "splat_mega64_kernel",
+        dom = {"stream": "splat_stream_kernel", "mid": "splat_mid_kernel",
+               "mega": "splat_mega64_kernel" if args.mode == "density" else "splat_mega_kernel",
                "huge": "splat_huge_kernel" if args.mode == "rgb" else "splat_huge2_kernel"}[dom]
     bytes_per_launch = B_ALG[args.mode] * n_per
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0

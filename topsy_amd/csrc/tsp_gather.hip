@@ -25,6 +25,12 @@ template <int T> __device__ __forceinline__ int dpp_quad_bcast(int v) {       //
 }
 template <int T> __device__ __forceinline__ float dpp_quad_bcast(float v) { return __int_as_float(dpp_quad_bcast<T>(__float_as_int(v))); }
 
+#ifndef TSP_FOLD_H
+#define TSP_FOLD_H 1024      // footprints a float32 accumulator of kernel H holds when it has no register totals (rgb)
+#endif
+#ifndef TSP_H_OCC3
+#define TSP_H_OCC3 4         // waves per SIMD of kernel H's rgb build
+#endif
 constexpr int HT = 512;              // threads per workgroup of kernel H (8 waves share one quad table)
 constexpr int HTILE_W = 128;         // its tile is 128 pixels wide: 32 lanes x 4 pixels
 
@@ -33,7 +39,7 @@ constexpr int HTILE_W = 128;         // its tile is 128 pixels wide: 32 lanes x 
 //        by 4*PXH pixels, so the taller block costs ~30 % fewer instructions per pixel; it is used
 //        when the accumulators still fit the 128-VGPR budget of a 512-thread workgroup (NACC == 1).
 template <int MODE, int NACC, int PXH>
-__global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
+__global__ __launch_bounds__(HT, (NACC == 3) ? TSP_H_OCC3 : 4) void splat_huge_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
     constexpr int NPX = 4 * PXH;
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(HT, 4) void splat_huge_kernel(TileArgs a) {
     // for the taller pixel block, straight into the render target (PXH == 8).
     constexpr bool REG_TOTALS = (PXH == 4) && (NACC < 3);     // rgb: 3 accumulators + counter leave no room for totals
     constexpr int NTOT = REG_TOTALS ? NPX : 1;
-    constexpr int FOLD_EVERY = REG_TOTALS ? 64 : 1024;
+    constexpr int FOLD_EVERY = REG_TOTALS ? 64 : TSP_FOLD_H;
     float acc[NPX][NACC], tot[NTOT][NACC];
 #pragma unroll
     for (int p = 0; p < NPX; ++p) {
