@@ -165,7 +165,7 @@ void tsp_destroy(tsp_context *ctx) {
     free_particles(ctx);
     void *ptrs[] = {ctx->image, ctx->image64, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->lut2d, ctx->scratch,
                     ctx->ws.mid_geom, ctx->ws.mid_w, ctx->ws.huge_geom, ctx->ws.huge_w, ctx->ws.seg_count, ctx->ws.seg_offset,
-                    ctx->ws.seg_bbox, ctx->ws.band_count, ctx->ws.band_list, ctx->ws.range_prefix, ctx->ws.count_diff, ctx->ws.count_band, ctx->sort_keys, ctx->sort_keys_alt, ctx->sort_tmp};
+                    ctx->ws.seg_bbox, ctx->ws.band_count, ctx->ws.band_list, ctx->ws.range_prefix, ctx->ws.count_diff, ctx->ws.count_band, ctx->ws.int_d2, ctx->ws.int_part, ctx->int_tables, ctx->sort_keys, ctx->sort_keys_alt, ctx->sort_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &e : ctx->ev)
@@ -203,6 +203,15 @@ int tsp_set_kernel_mips(tsp_context *ctx, const float *lut, int n0, int n_levels
                 if (memcmp(&lut[off + j * n + i], &lut[off + j * n + (n - 1 - i)], 4) || memcmp(&lut[off + j * n + i], &lut[off + (n - 1 - j) * n + i], 4)) { sym = false; break; }
     }
     ctx->lut_mirror_symmetric = sym;
+    {   // kernel I (option integrated_px): breakpoint strengths of the level-0 image and their prefix sums, in float64
+        std::vector<double> tables;
+        integrated_tables(lut, tables);
+        ctx->int_edge[0] = ctx->int_edge[1] = 0;
+        for (int q = 0; q < 66; ++q)
+            if (tables[(size_t)q * INT_S0_STRIDE] != 0.0 || tables[(size_t)q * INT_S0_STRIDE + 65] != 0.0) ctx->int_edge[q >> 6] |= 1ull << (q & 63);
+        if (!ctx->int_tables) TSP_HIP(hipMalloc((void **)&ctx->int_tables, tables.size() * sizeof(double)));
+        TSP_HIP(hipMemcpy(ctx->int_tables, tables.data(), tables.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     return TSP_OK;
 }
 
@@ -693,6 +702,12 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         // class boundary H2 (rgb: H) / H3 in pixels (>= 64; 0 = no H3) for density / two-channel / rgb renders
         TSP_REQUIRE(value == 0 || (value >= 64 && value <= (1 << 20)), TSP_EINVAL, "%s out of range", name);
         (name[6] == '2' ? ctx->p_mega2 : (name[6] == '_' && name[7] == 'r' ? ctx->p_mega_rgb : ctx->p_mega)) = (float)value;
+        return TSP_OK;
+    }
+    if (!strcmp(name, "integrated_px")) {     // density footprints at least this wide go through kernel I (0 = off, else >= 128: below that the
+        // clamp-to-edge rim of the square is narrower than a pixel and the edge jumps are no longer pure steps)
+        TSP_REQUIRE(value == 0 || (value >= 128 && value <= 1000000), TSP_EINVAL, "integrated_px must be 0 or >= 128, got %lld", (long long)value);
+        ctx->integrated_px = (float)value;
         return TSP_OK;
     }
     if (!strcmp(name, "mega_variant")) {

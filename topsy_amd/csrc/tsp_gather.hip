@@ -1239,7 +1239,8 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
             if (ctx->rgb_mega_variant == 1) rc = launch_mega<MODE, 3, 2, 2>(ctx, ta, n_mega);
             else if (ctx->rgb_mega_variant == 2) rc = launch_mega<MODE, 3, 2, 3>(ctx, ta, n_mega);
             else rc = launch_mega<MODE, 3, 1, 3>(ctx, ta, n_mega);
-        } else if (second_channel) rc = launch_mega<MODE, 2, 2, 3>(ctx, ta, n_mega);      // 64 accumulator + 32 scratch registers: 3 waves/SIMD (4 would spill)
+        } else if (integrated_active(ctx, MODE, second_channel)) rc = launch_integrated(ctx, ta, mega_geom, n_mega);   // option: kernel I
+        else if (second_channel) rc = launch_mega<MODE, 2, 2, 3>(ctx, ta, n_mega);      // 64 accumulator + 32 scratch registers: 3 waves/SIMD (4 would spill)
         // density: 64 x 64 strips (column factors and parameters prepared once per 4096 pixels) once there are enough records to
         // keep their fewer, longer workgroups busy: 1.25e8 particles 6.3 -> 6.0 ms, 1e9: 18.2 -> 17.3 ms, but 1e7: 2.1 -> 2.25 ms
         else if (ctx->mega_variant == 2 || (ctx->mega_variant == 0 && n_mega >= 40000)) rc = launch_mega64<MODE, 4>(ctx, ta, n_mega);

@@ -69,6 +69,8 @@ struct Workspace {     // per-context scratch of the three-class pipeline (grown
     int64_t range_capacity = 0;
     int *count_diff = nullptr;          // rgb: (R+1)^2 corner-difference image of the huge footprints' pixel rectangles
     int *count_band = nullptr;          // rgb: per (64-row band, column) sums of its row-scanned form
+    double *int_d2 = nullptr;           // kernel I: R x R second-difference image (zero between render blocks)
+    void *int_part = nullptr;           // kernel I: per (32-row segment, column) partial sums of the column pass
 };
 
 }  // namespace tsp
@@ -114,6 +116,9 @@ struct tsp_context {
     float p_mega = 512.0f;            // density renders: footprints at least this wide go to kernel H3 (matrix cores); 0 = all to H2
     float p_mega2 = 256.0f;           // the same for two-channel renders (weighted, depth): their H2 pays 5 instead of 2 FMAs per pixel row
     float p_mega_rgb = 128.0f;        // ... and for rgb (kernel H below, kernel H3 with three accumulator sets above)
+    float integrated_px = 0.0f;       // option: density footprints at least this wide (>= 128) go through kernel I (second differences + prefix sums, tsp_integrated.hip); 0 = off
+    unsigned long long int_edge[2] = {0, 0};   // kernel I: rows of S0 with a non-zero edge jump (bit q of 66)
+    double *int_tables = nullptr;     // kernel I: breakpoint strengths of the level-0 kernel image and their prefix sums (integrated_tables)
     int mega_variant = 0;             // density: 0 = auto, 1 = kernel H3 on 64 x 32 strips, 2 / 3 = on 64 x 64 strips at 4 / 3 waves per SIMD
     int rgb_mega_variant = 3;         // rgb: 0 = every footprint >= 64 px on kernel H; 1-3: those >= p_mega on kernel H3 with three accumulator sets
     int huge_variant = 1;             // 0: kernel H (per-pixel gather, A/B only), 1: kernels H2 (64x16 strips) + H3, 2: H2 with 64x32 strips (density)
@@ -162,4 +167,10 @@ int launch_image_convert(tsp_context *ctx, bool to_float);
 int tile_periodic(tsp_context *ctx, int n, const float *h_offsets, const float *h_weights);
 int content_sort(tsp_context *ctx, int kind, float scale, int64_t *n_finite, int64_t *n_nonpositive);   // image64 -> image (true) or image -> image64 (false)
 int ensure_array(float **p, int64_t n);
+constexpr int INT_S0_STRIDE = 68;   // doubles per row of kernel I's breakpoint tables (66 used)
+constexpr int INT_O_PA = 66 * INT_S0_STRIDE, INT_O_PB = INT_O_PA + 66 * INT_S0_STRIDE, INT_O_PAY = INT_O_PB + 66 * INT_S0_STRIDE;
+constexpr int INT_O_PBY = INT_O_PAY + 65 * INT_S0_STRIDE, INT_O_M = INT_O_PBY + 65 * INT_S0_STRIDE;
+constexpr int INT_TABLE_DOUBLES = INT_O_M + 65 * 65 * 4;
+bool integrated_supported(const tsp_context *ctx);
+void integrated_tables(const float *mip0, std::vector<double> &out);
 }  // namespace tsp
