@@ -696,7 +696,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
         bool hit;
         {
             const float sdx = fmaxf(fmaxf(sx0 - g.x, g.x - sx1), 0.0f), sdy = fmaxf(fmaxf(sy0 - g.y, g.y - sy1), 0.0f);
-            hit = g.z >= a.p_lo && sdx < g_half && sdy < g_half && !(a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * g.z * g.z);
+            hit = g.z >= a.p_lo && g.z < a.p_hi && sdx < g_half && sdy < g_half && !(a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * g.z * g.z);
         }
         unsigned long long hits = __ballot(hit);
         if (hits == 0ull) continue;
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega64_kernel(TileArgs a) {
         bool hit;
         {
             const float sdx = fmaxf(fmaxf(sx0 - g.x, g.x - sx1), 0.0f), sdy = fmaxf(fmaxf(sy0 - g.y, g.y - sy1), 0.0f);
-            hit = g.z >= a.p_lo && sdx < g_half && sdy < g_half && !(a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * g.z * g.z);
+            hit = g.z >= a.p_lo && g.z < a.p_hi && sdx < g_half && sdy < g_half && !(a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * g.z * g.z);
         }
         unsigned long long hits = __ballot(hit);
         if (hits == 0ull) continue;
@@ -1234,13 +1234,23 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
     TSP_HIP(hipEventRecord(ctx->ev[10], st));
     if (n_mega > 0) {                           // kernel H3 (matrix cores): P >= p_mega, the tail end of the huge list
         ta.geom = mega_geom; ta.w = mega_w; ta.n_records = n_mega;
-        if constexpr (MODE == TSP_MODE_RGB) {
+        // option integrated_px: kernel I takes the records at least that wide, the matrix cores what is left of the mega list
+        // below it (rgb 128 px ... integrated_px; nothing when the mode's own boundary is not below it)
+        const bool integ = integrated_active(ctx);
+        const float pm_mode = (MODE == TSP_MODE_RGB) ? (ctx->rgb_mega_variant > 0 ? ctx->p_mega_rgb : 0.0f) : (second_channel ? ctx->p_mega2 : ctx->p_mega);
+        const bool mfma_part = !integ || (pm_mode > 0.0f && pm_mode < ctx->integrated_px);
+        if (integ) {
+            rc = launch_integrated(ctx, ta, mega_geom, mega_w, MODE == TSP_MODE_RGB ? 2 : (second_channel ? 1 : 0), n_mega, ctx->integrated_px);
+            if (rc) return rc;
+            ta.p_hi = ctx->integrated_px;
+        }
+        if (!mfma_part) {
+        } else if constexpr (MODE == TSP_MODE_RGB) {
             // three accumulator sets (96 registers for a 64 x 32 strip): 2-3 waves per SIMD of the 512-entry register file
             if (ctx->rgb_mega_variant == 1) rc = launch_mega<MODE, 3, 2, 2>(ctx, ta, n_mega);
             else if (ctx->rgb_mega_variant == 2) rc = launch_mega<MODE, 3, 2, 3>(ctx, ta, n_mega);
             else rc = launch_mega<MODE, 3, 1, 3>(ctx, ta, n_mega);
-        } else if (integrated_active(ctx, MODE, second_channel)) rc = launch_integrated(ctx, ta, mega_geom, n_mega);   // option: kernel I
-        else if (second_channel) rc = launch_mega<MODE, 2, 2, 3>(ctx, ta, n_mega);      // 64 accumulator + 32 scratch registers: 3 waves/SIMD (4 would spill)
+        } else if (second_channel) rc = launch_mega<MODE, 2, 2, 3>(ctx, ta, n_mega);      // 64 accumulator + 32 scratch registers: 3 waves/SIMD (4 would spill)
         // density: 64 x 64 strips (column factors and parameters prepared once per 4096 pixels) once there are enough records to
         // keep their fewer, longer workgroups busy: 1.25e8 particles 6.3 -> 6.0 ms, 1e9: 18.2 -> 17.3 ms, but 1e7: 2.1 -> 2.25 ms
         else if (ctx->mega_variant == 2 || (ctx->mega_variant == 0 && n_mega >= 40000)) rc = launch_mega64<MODE, 4>(ctx, ta, n_mega);

@@ -35,12 +35,15 @@ constexpr size_t INT_LDS_BYTES = 156 * 1024;   // LDS of a band: 17 + 2 rows of 
 
 struct IntArgs {
     const float4 *geom;
+    const float *wq;                     // per record: q (two-channel modes) or (g, b) / h^2 (rgb), as in the tile-gather kernels
+    int wmode;                           // 0: density only, 1: second channel = w q, 2: rgb
     long long n_records;
     const double *T;                     // the breakpoint tables (integrated_tables)
     unsigned long long edge_lo, edge_hi; // bit q (of 66): row q of S0 has a non-zero edge jump (S0[q][0] or S0[q][65])
-    double *D2;                          // [R][R] second-difference image
+    double *D2;                          // [channels][R][R] second-difference images (blockIdx.y = channel)
     Counters *cnt;
-    int R, BH, STR, split, count_frag;
+    int R, BH, STR, TW, nx, split, count_frag;   // tile = BH rows x TW columns (nx column parts per band), LDS row stride STR = TW + 2
+    float p_lo;                          // records narrower than this belong to the matrix-core kernels
 };
 
 __device__ __forceinline__ void ladd64(double *addr, double v) {
@@ -58,9 +61,11 @@ __global__ __launch_bounds__(IT) void splat_integrated_kernel(IntArgs a) {
     // are ghost rows that belong to the neighbouring bands (which add them themselves) and are not written back
     extern __shared__ __attribute__((aligned(16))) double itile[];     // [BH + 2][STR]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int band = blockIdx.x / a.split, sp = blockIdx.x % a.split;
+    const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split, ch = blockIdx.y;
+    const int band = tile_id / a.nx, part = tile_id % a.nx;
     const int R = a.R, STR = a.STR;
     const int by0 = band * a.BH, by1 = min(by0 + a.BH, R), bh = by1 - by0;
+    const int tx0 = part * a.TW, tx1 = min(tx0 + a.TW, R);   // the tile's columns; LDS also holds a ghost column either side
     for (int i = tid; i < (a.BH + 2) * STR; i += IT) itile[i] = 0.0;
     __syncthreads();
     unsigned long long n_frag = 0;
@@ -72,15 +77,36 @@ __global__ __launch_bounds__(IT) void splat_integrated_kernel(IntArgs a) {
     for (long long run0 = 0; run0 * vsplit < n_runs; run0 += 64 / HDEAL) {
         const long long ri = ((run0 + lane / HDEAL) * vsplit + vsp) * HDEAL + (lane & (HDEAL - 1));
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ri < a.n_records) g = a.geom[ri];
+        if (ri < a.n_records) {
+            g = a.geom[ri];
+            // this workgroup's channel: the record's weight in it rides in g.w
+            if (ch == 1) g.w = (a.wmode == 2) ? a.wq[ri * 2] : g.w * a.wq[ri];
+            else if (ch == 2) g.w = a.wq[ri * 2 + 1];
+        }
         int ilo = 1, ihi = 0, jlo = 1, jhi = 0;
         bool hit = false;
-        if (g.z > 0.0f) {
+        if (g.z >= a.p_lo && g.z > 0.0f) {
             const float hf = 0.5f * g.z;
             cover_range(g.x, hf, R, ilo, ihi);
             cover_range(g.y, hf, R, jlo, jhi);
             // rows that receive entries: jlo .. jhi + 2 (the bottom jump sits on rows jhi + 1, jhi + 2)
-            hit = ilo <= ihi && jlo <= jhi && jlo < by1 && jhi + 2 >= by0;
+            // ... and columns ilo .. ihi + 2
+            hit = ilo <= ihi && jlo <= jhi && jlo < by1 && jhi + 2 >= by0 && ilo < tx1 && ihi + 2 >= tx0;
+            if (hit && a.count_frag && ch == 0) {      // the fragments of this record inside this tile (every record meets every tile once)
+                const int rows = min(jhi, by1 - 1) - max(jlo, by0) + 1, cols = min(ihi, tx1 - 1) - max(ilo, tx0) + 1;
+                if (rows > 0 && cols > 0) n_frag += (unsigned long long)rows * (unsigned long long)cols;
+            }
+            if (hit && g.z > 64.0f * (float)(a.BH + 2)) {
+                // breakpoints further apart than the band is tall: most bands hold none of them.  A breakpoint at t lands on rows
+                // ceil(t), ceil(t) + 1; it concerns this band when by0 - 2 < t <= by1 - 1 (band 0: also everything above the image).
+                // Conservative float32 test (the exact one follows per hit); the jumps sit on rows jlo and jhi + 1.
+                const float st = g.z * (1.0f / 64.0f), t0 = 0.5f * st - hf - 0.5f + g.y;
+                const float blo = by0 == 0 ? 0.0f : __builtin_floorf(((float)(by0 - 2) - t0) / st - 0.01f) + 1.0f;
+                const float bhi = __builtin_floorf(((float)(by1 - 1) - t0) / st + 0.01f);
+                const bool ramp = bhi >= fmaxf(blo, 0.0f) && blo <= 63.0f;
+                const bool jump = (jlo >= by0 - 1 && jlo < by1) || (jhi + 1 >= by0 - 1 && jhi + 1 < by1);
+                hit = ramp || jump;
+            }
         }
         unsigned long long hits = __ballot(hit);
         while (hits) {
@@ -110,8 +136,10 @@ __global__ __launch_bounds__(IT) void splat_integrated_kernel(IntArgs a) {
             int col = (int)cxc;
             const double A0 = alpha * fx, A1 = alpha - A0;
             const int a_c = __popcll(__ballot(xcl));                    // texel centres 0 .. a_c - 1 are left of the viewport
-            bool v0 = col < R, v1 = col + 1 < R;
-            if (xcl && lane != 0) v0 = v1 = false;                      // lane 0 carries their sum (PA / PB below)
+            // both of the lane's columns lie in the tile or its ghost columns (which the neighbouring tile fills itself)
+            bool vx = col >= tx0 - 1 && col < tx1;
+            if (xcl && lane != 0) vx = false;                           // lane 0 carries their sum (PA / PB below)
+            col -= tx0 - 1;
             // ---- y breakpoints: lane b ----
             const double ty = __builtin_fma((double)lane, step, t0y);
             const double cyr = __builtin_ceil(ty);
@@ -124,24 +152,22 @@ __global__ __launch_bounds__(IT) void splat_integrated_kernel(IntArgs a) {
             const unsigned long long yclm = __ballot(cyr < 0.0);
             const int b_c = __popcll(yclm);
             const unsigned long long qmask = __ballot(row >= by0 - 1 && row < by1 && row < R) & ~yclm;
-            const int c2 = lane ? colR : colL;                          // lanes 0 / 1: the jump at the left / right edge
-            const bool allv = __ballot(v0 && v1) == ~0ull;
+            const int c2g = lane ? colR : colL;                         // lanes 0 / 1: the jump at the left / right edge
+            const bool vs = c2g >= tx0 - 1 && c2g < tx1;
+            const int c2 = c2g - (tx0 - 1);
+            const bool allv = __ballot(vx) == ~0ull;
 
             // one y breakpoint: the lane's four entries (row rq: e00 at col, e10 at col + 1; row rq + 1: e01, e11) and,
             // on lanes 0 / 1, the edge jumps (u0s, -u0s on row rq; u1s, -u1s on row rq + 1)
             auto emit = [&](int rq, double e00, double e10, double e01, double e11, bool steps, double u0s, double u1s) {
                 const int roff = (rq - by0 + 1) * STR;
                 double *d = itile + roff + col;
-                if (allv) {                                             // the whole footprint width is on screen: no lane masks
+                if (allv || vx) {                                       // (allv: the whole footprint width is in the tile, no lane mask)
                     ladd64(d, e00); ladd64(d + 1, e10); ladd64(d + STR, e01); ladd64(d + STR + 1, e11);
-                } else {
-                    if (v0) { ladd64(d, e00); ladd64(d + STR, e01); }
-                    if (v1) { ladd64(d + 1, e10); ladd64(d + STR + 1, e11); }
                 }
-                if (steps && lane < 2) {
+                if (steps && lane < 2 && vs) {
                     double *e = itile + roff + c2;
-                    if (c2 < R) { ladd64(e, u0s); ladd64(e + STR, u1s); }
-                    if (c2 + 1 < R) { ladd64(e + 1, -u0s); ladd64(e + STR + 1, -u1s); }
+                    ladd64(e, u0s); ladd64(e + 1, -u0s); ladd64(e + STR, u1s); ladd64(e + STR + 1, -u1s);
                 }
             };
             if (b_c > 0 && by0 == 0) {
@@ -206,21 +232,21 @@ __global__ __launch_bounds__(IT) void splat_integrated_kernel(IntArgs a) {
                     b = bn; s = sn; x = xn;
                 }
             }
-            if (a.count_frag && lane == 0) {
-                const int rows = min(rowR - 1, by1 - 1) - max(rowL, by0) + 1;
-                if (rows > 0) n_frag += (unsigned long long)rows * (unsigned long long)(colR - colL);
-            }
         }
     }
     const int any = __syncthreads_or(touched ? 1 : 0);
     if (any) {
-        for (int i = tid; i < bh * STR; i += IT) {
-            const int r = i / STR, c = i - r * STR;
-            const double v = itile[i + STR];
-            if (c < R && v != 0.0) gatomic_add(a.D2 + (size_t)(by0 + r) * R + c, v);
+        const int tw = tx1 - tx0;
+        for (int i = tid; i < bh * tw; i += IT) {
+            const int r = i / tw, c = i - r * tw;
+            const double v = itile[(r + 1) * STR + c + 1];
+            if (v != 0.0) gatomic_add(a.D2 + ((size_t)ch * R + (by0 + r)) * R + tx0 + c, v);
         }
     }
-    if (a.count_frag && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+    if (a.count_frag) {
+        for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
+        if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+    }
 }
 
 // ---- the double prefix sums -------------------------------------------------------------------------------------------------
@@ -232,7 +258,7 @@ __global__ __launch_bounds__(256) void integrate_rows_kernel(double *__restrict_
     __shared__ double s1[256], s2[256];
     __shared__ int sl[256];
     const int tid = threadIdx.x;
-    double *row = D2 + (size_t)blockIdx.x * R;
+    double *row = D2 + ((size_t)blockIdx.y * R + blockIdx.x) * R;
     const int per = (R + 255) / 256, b = min(tid * per, R), e = min(b + per, R);
     double r1 = 0.0, r2 = 0.0;
     for (int i = b; i < e; ++i) { r1 += row[i]; r2 += r1; }
@@ -258,16 +284,21 @@ constexpr int ISEG = 32;                 // rows per segment of the column pass
 __global__ __launch_bounds__(256) void integrate_cols_partial_kernel(const double *__restrict__ D2, int R, double2 *__restrict__ part) {
     const int i = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y;
     if (i >= R) return;
+    D2 += (size_t)blockIdx.z * R * R;
+    part += (size_t)blockIdx.z * gridDim.y * R;
     const int j0 = seg * ISEG, j1 = min(j0 + ISEG, R);
     double r1 = 0.0, r2 = 0.0;
     for (int j = j0; j < j1; ++j) { r1 += D2[(size_t)j * R + i]; r2 += r1; }
     part[(size_t)seg * R + i] = make_double2(r1, r2);
 }
-// pass 2: carry in the segments above, finish, add into channel 0 of the render target and clear D2 for the next block
+// pass 2: carry in the segments above, finish, add into the channel of the render target and clear D2 for the next block
 __global__ __launch_bounds__(256) void integrate_cols_apply_kernel(double *__restrict__ D2, int R, const double2 *__restrict__ part,
                                                                    double *__restrict__ img, int C) {
     const int i = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y;
     if (i >= R) return;
+    D2 += (size_t)blockIdx.z * R * R;
+    part += (size_t)blockIdx.z * gridDim.y * R;
+    img += blockIdx.z;                       // channel c of the render target
     double c1 = 0.0, c2 = 0.0;
     for (int s = 0; s < seg; ++s) {
         const double2 p = part[(size_t)s * R + i];
@@ -285,25 +316,33 @@ __global__ __launch_bounds__(256) void integrate_cols_apply_kernel(double *__res
 }
 
 bool integrated_supported(const tsp_context *ctx) {
-    return ctx->int_tables != nullptr && ctx->R >= 64 && (size_t)(ctx->R + 2) * 4 * sizeof(double) <= INT_LDS_BYTES;
+    return ctx->int_tables != nullptr && ctx->R >= 64 && ctx->R <= 65536;
 }
 
-int launch_integrated(tsp_context *ctx, const TileArgs &ta, const float4 *geom, long long n_records) {
+int launch_integrated(tsp_context *ctx, const TileArgs &ta, const float4 *geom, const float *wq, int wmode, long long n_records, float p_lo) {
     Workspace &ws = ctx->ws;
     hipStream_t st = ctx->stream;
     const int R = ctx->R;
     TSP_REQUIRE(integrated_supported(ctx), TSP_ESTATE, "kernel I is not available for this context");
+    const int nch = wmode == 0 ? 1 : (wmode == 1 ? 2 : 3);
     const int nseg = (R + ISEG - 1) / ISEG;
-    if (!ws.int_d2) {
-        TSP_HIP(hipMalloc((void **)&ws.int_d2, (size_t)R * R * sizeof(double)));
-        TSP_HIP(hipMalloc((void **)&ws.int_part, (size_t)nseg * R * sizeof(double2)));
-        TSP_HIP(hipMemsetAsync(ws.int_d2, 0, (size_t)R * R * sizeof(double), st));
+    if (ws.int_channels < nch) {
+        if (ws.int_d2) TSP_HIP(hipFree(ws.int_d2));
+        if (ws.int_part) TSP_HIP(hipFree(ws.int_part));
+        ws.int_d2 = nullptr; ws.int_part = nullptr; ws.int_channels = 0;
+        TSP_HIP(hipMalloc((void **)&ws.int_d2, (size_t)nch * R * R * sizeof(double)));
+        TSP_HIP(hipMalloc((void **)&ws.int_part, (size_t)nch * nseg * R * sizeof(double2)));
+        TSP_HIP(hipMemsetAsync(ws.int_d2, 0, (size_t)nch * R * R * sizeof(double), st));
+        ws.int_channels = nch;
     }
     IntArgs ia;
-    ia.geom = geom; ia.n_records = n_records;
-    ia.T = ctx->int_tables;
+    ia.geom = geom; ia.wq = wq; ia.wmode = wmode; ia.n_records = n_records;
+    ia.T = ctx->int_tables; ia.p_lo = p_lo;
     ia.D2 = ws.int_d2; ia.cnt = ta.cnt; ia.R = R; ia.count_frag = ta.count_frag;
-    ia.STR = R + 2;
+    // tiles of at most 1024 columns (+ a ghost column either side): 17 rows of them fit the LDS, and a footprint meets P / 17 + 1 bands
+    ia.nx = (R + 1023) / 1024;
+    ia.TW = (R + ia.nx - 1) / ia.nx;
+    ia.STR = ia.TW + 2;
     const int bh = (int)(INT_LDS_BYTES / ((size_t)ia.STR * sizeof(double))) - 2;     // + two ghost rows
     ia.BH = bh;
     ia.edge_lo = ctx->int_edge[0]; ia.edge_hi = ctx->int_edge[1];
@@ -313,16 +352,17 @@ int launch_integrated(tsp_context *ctx, const TileArgs &ta, const float4 *geom, 
         TSP_HIP(hipFuncSetAttribute((const void *)splat_integrated_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)INT_LDS_BYTES));
         ctx->kernel_attr_done |= 1u << 16;
     }
+    // two workgroups per CU and channel-set: bands differ in work, and one round of 256 long workgroups measured 1.7x slower
     int split = ctx->mega_split;
-    if (split <= 0) split = std::max(1, (ctx->cu_count * 2 + n_bands - 1) / n_bands);
+    if (split <= 0) split = std::max(1, (ctx->cu_count * 2 + n_bands * ia.nx * nch - 1) / (n_bands * ia.nx * nch));
     const long long runs = (n_records + HDEAL - 1) / HDEAL;
     split = (int)std::min<long long>(split, std::max<long long>((runs + IWAVES - 1) / IWAVES, 1));
     ia.split = split;
-    hipLaunchKernelGGL(splat_integrated_kernel, dim3(n_bands * split), dim3(IT), smem, st, ia);
+    hipLaunchKernelGGL(splat_integrated_kernel, dim3(n_bands * ia.nx * split, nch), dim3(IT), smem, st, ia);
     TSP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(integrate_rows_kernel, dim3(R), dim3(256), 0, st, ws.int_d2, R);
-    hipLaunchKernelGGL(integrate_cols_partial_kernel, dim3((R + 255) / 256, nseg), dim3(256), 0, st, ws.int_d2, R, (double2 *)ws.int_part);
-    hipLaunchKernelGGL(integrate_cols_apply_kernel, dim3((R + 255) / 256, nseg), dim3(256), 0, st, ws.int_d2, R, (const double2 *)ws.int_part,
+    hipLaunchKernelGGL(integrate_rows_kernel, dim3(R, nch), dim3(256), 0, st, ws.int_d2, R);
+    hipLaunchKernelGGL(integrate_cols_partial_kernel, dim3((R + 255) / 256, nseg, nch), dim3(256), 0, st, ws.int_d2, R, (double2 *)ws.int_part);
+    hipLaunchKernelGGL(integrate_cols_apply_kernel, dim3((R + 255) / 256, nseg, nch), dim3(256), 0, st, ws.int_d2, R, (const double2 *)ws.int_part,
                        ctx->image64, ctx->C);
     TSP_HIP(hipGetLastError());
     return TSP_OK;

@@ -69,7 +69,8 @@ struct Workspace {     // per-context scratch of the three-class pipeline (grown
     int64_t range_capacity = 0;
     int *count_diff = nullptr;          // rgb: (R+1)^2 corner-difference image of the huge footprints' pixel rectangles
     int *count_band = nullptr;          // rgb: per (64-row band, column) sums of its row-scanned form
-    double *int_d2 = nullptr;           // kernel I: R x R second-difference image (zero between render blocks)
+    double *int_d2 = nullptr;           // kernel I: [int_channels] R x R second-difference images (zero between render blocks)
+    int int_channels = 0;
     void *int_part = nullptr;           // kernel I: per (32-row segment, column) partial sums of the column pass
 };
 

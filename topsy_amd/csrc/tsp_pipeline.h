@@ -81,10 +81,10 @@ struct TileArgs {
 int launch_gather_kernels(tsp_context *ctx, TileArgs ta, int mode, bool second_channel, const float4 *huge_geom,
                           const float *huge_w, long long n_huge, const float4 *mega_geom, const float *mega_w, long long n_mega);
 
-// Kernel I (tsp_integrated.hip, option `integrated_px`): the mega records of a density render through second differences.
-int launch_integrated(tsp_context *ctx, const TileArgs &ta, const float4 *geom, long long n_records);
-inline bool integrated_active(const tsp_context *ctx, int mode, bool second_channel) {
-    return mode == TSP_MODE_WEIGHTED && !second_channel && ctx->integrated_px >= 128.0f && ctx->huge_variant != 0 && integrated_supported(ctx);
+// Kernel I (tsp_integrated.hip, option `integrated_px`): the mega records through second differences, one pass per channel.
+int launch_integrated(tsp_context *ctx, const TileArgs &ta, const float4 *geom, const float *wq, int wmode, long long n_records, float p_lo);
+inline bool integrated_active(const tsp_context *ctx) {
+    return ctx->integrated_px >= 128.0f && ctx->huge_variant != 0 && integrated_supported(ctx);
 }
 
 }  // namespace tsp

@@ -898,7 +898,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         TSP_HIP(hipMemsetAsync(ws.band_count, 0, NBANDS * sizeof(int), st));
         sa.cnt = ctx->counters; sa.p_small = ctx->p_small; {
             float pm = (MODE == TSP_MODE_RGB) ? (ctx->rgb_mega_variant > 0 ? ctx->p_mega_rgb : 0.0f) : (second_channel ? ctx->p_mega2 : ctx->p_mega);
-            if (integrated_active(ctx, MODE, second_channel)) pm = ctx->integrated_px;     // kernel I takes the mega records
+            if (integrated_active(ctx)) pm = (pm > 0.0f && pm < ctx->integrated_px) ? pm : ctx->integrated_px;     // kernel I takes the mega records >= integrated_px
             sa.p_mega = (ctx->huge_variant != 0 && pm > 0.0f) ? pm : __builtin_inff();
         } sa.count_frag = ctx->count_fragments ? 1 : 0;
         sa.emit_small = (attempt == 0 && !ctx->debug_no_raster) ? 1 : 0;
