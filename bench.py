@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--generic", action="store_true", help="use the generic (global-atomic) kernel")
     ap.add_argument("--no-reorder", action="store_true")
+    ap.add_argument("--integrated-px", type=int, default=0,
+                    help="option integrated_px of the library (kernel I for footprints at least this wide); 0 = the default path")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline frames: no extra configurations, no CPU baseline (what the profiler runs, so "
                          "that every kernel instance in a profile belongs to the headline workload)")
@@ -131,6 +133,8 @@ def main():
     if not args.no_reorder:
         ctx.reorder_spatial(num_strata(n_per), 1337)       # load-time ordering, as the product path does
     t_setup = time.time() - t_setup
+    if args.integrated_px:
+        ctx.set_option("integrated_px", args.integrated_px)
 
     if world > 1:
         ids = [ctx.comm_unique_id() if rank == 0 else None]
@@ -219,6 +223,7 @@ def main():
     workload_name = (f"{n_total:.4g} dm particles ({n_per:.4g}/GPU), {args.mode}, {R}^2 buffer, camera A "
                      f"(scale {args.scale:g}), reference TestDataLoader h-law"
                      + (f", h capped at {args.h_cap_px:g} px" if args.h_cap_px > 0 else "")
+                     + (f", option integrated_px = {args.integrated_px}" if args.integrated_px else "")
                      + ", splat + " + ("RCCL image reduce + " if world > 1 else "") + "colormap")
     measured_peak = ctx.measure_read_bandwidth(4 << 30, 5)
     # HBM bytes of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE doubled as
@@ -259,13 +264,17 @@ def main():
         "kernel_ms": means,
         "setup_s": t_setup,
     }
-    if mfma_per_launch and means["mega"] > 0:
+    if mfma_per_launch and means["mega"] > 0 and not args.integrated_px:
         # the matrix-core kernel against ITS roofline: instruction count from the committed PMC pass, duration live
         tflops = mfma_per_launch * 2 * 32 * 32 * 2 / (means["mega"] * 1e-3) / 1e12
         result["roofline_mega"] = {"bound": "mfma", "kernel": mega_kernel, "achieved": tflops, "peak": MFMA_F32_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": tflops / MFMA_F32_PEAK_TFLOPS, "kernel_ms": means["mega"],
                                    "mfma_instructions_per_launch": mfma_per_launch}
-    extras = world == 1 and not args.generic and not args.headline_only and args.h_cap_px <= 0
+    extras = world == 1 and not args.generic and not args.headline_only and args.h_cap_px <= 0 and not args.integrated_px
+    if extras and args.mode == "density":
+        # the opt-in kernel I (second differences + prefix sums for footprints >= 256 px) on the SAME resident snapshot:
+        # reported beside the headline, never as `value` (its accuracy contract is weaker, tests/test_gpu_integrated.py)
+        result["integrated_option"] = integrated_line(ctx, M, sf, mode, n_per)
     if extras:
         # the same positions with footprints capped at 8 px isolate the streaming
         # regime (kernel S only); reported next to the headline, never as `value`
@@ -298,6 +307,27 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def integrated_line(ctx, M, sf, mode, n_per, px=256, frames=10):
+    ctx.render(M, sf, clear=True, mode=mode)
+    exact = ctx.read_image()[..., 0].astype(np.float64)
+    ctx.set_option("integrated_px", px)
+    ms, mega = [], []
+    for i in range(frames + 1):
+        t = ctx.render(M, sf, clear=True, mode=mode)
+        if i:
+            ms.append(t); mega.append(ctx.stats()["ms_mega"])
+    st = ctx.stats()
+    fast = ctx.read_image()[..., 0].astype(np.float64)
+    ctx.set_option("integrated_px", 0)
+    lit = exact > 0
+    rel = np.abs(fast - exact)[lit] / exact[lit]
+    return {"workload": f"the headline snapshot with the option integrated_px = {px} (footprints >= {px} px through kernel I)",
+            "ms_per_step": float(np.median(ms)), "value": n_per / (float(np.median(ms)) * 1e-3), "unit": "particles/s",
+            "kernel_I_ms": float(np.median(mega)), "records_through_kernel_I": int(st["n_mega"]),
+            "max_relative_difference_per_pixel_from_the_exact_kernels": float(rel.max()) if rel.size else 0.0,
+            "pixels_compared": int(lit.sum())}
 
 
 def hcapped_line(args, ctx, n_total, n_per, rank, M, sf, mode, measured_peak, cap_px=8.0, frames=10):

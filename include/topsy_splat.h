@@ -223,7 +223,11 @@ typedef struct {
     int64_t n_mega;        /* footprints handled by kernel H3 */
 } tsp_stats;
 int tsp_get_stats(tsp_context *ctx, tsp_stats *out);
-/* Enable fragment counting (adds atomics; off by default). */
+/* Options by name.  "count_fragments" (0/1): fragment counting (adds atomics; off by default).  "integrated_px" (0 = off, the
+ * default, or >= 128): footprints at least this many pixels wide are drawn by kernel I -- the sparse second differences of
+ * the bilinear footprint scattered and the image integrated twice along either axis -- instead of pixel by pixel; exact to
+ * ~1e-6 of a footprint's PEAK value rather than of every pixel's own value (tests/test_gpu_integrated.py).  The remaining
+ * names are tuning and measurement aids of the pipeline (class boundaries, workgroup counts; csrc/tsp_api.hip). */
 int tsp_set_option(tsp_context *ctx, const char *name, int64_t value);
 
 /* Streaming-read microbenchmark (float4 read-sum over `bytes` of device memory; best of a few launch shapes): returns GB/s.

@@ -123,6 +123,29 @@ def test_dense_scene_is_within_the_relative_tolerance(native, mips):
     ctx.close()
 
 
+def test_through_the_visualizer(monkeypatch):
+    """config.INTEGRATED_FOOTPRINT_PX reaches the context of a Visualizer; the 1000-particle reference scene zoomed to
+    scale 20 (footprints of hundreds of pixels at 200^2) against the default kernels."""
+    import topsy_amd
+    from topsy_amd import config
+    from topsy_amd.drawreason import DrawReason
+
+    def image():
+        vis = topsy_amd.test(1000, render_resolution=200)
+        vis.scale = 20.0
+        vis.rotate(0.0, 0.4)
+        vis.render_sph(DrawReason.EXPORT)
+        im = np.array(vis.get_sph_image(), dtype=np.float64)
+        n_mega = vis._sph._context.stats()["n_mega"]
+        vis.close()
+        return im, n_mega
+    ref, _ = image()
+    monkeypatch.setattr(config, "INTEGRATED_FOOTPRINT_PX", 128)
+    got, n_mega = image()
+    assert n_mega > 100
+    assert np.abs(got - ref).max() <= 1e-5 * ref.max(), np.abs(got - ref).max() / ref.max()
+
+
 def test_option_range(native, mips):
     ctx = native.Context(128, 2)
     ctx.set_kernel_mips(mips)

@@ -2,7 +2,7 @@
 """Condense gpurun_out/bench_prof (tools/profile_bench.sh) into small tracked files under profiles/."""
 import csv, collections, json, os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "round1"
-src = "gpurun_out/bench_prof"
+src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/bench_prof"      # a third argument (any) keeps profiles/latest_bench_counters.json as it is
 os.makedirs("profiles", exist_ok=True)
 
 
@@ -64,7 +64,8 @@ try:
 except Exception as ex:
     out["bench_line"] = str(ex)
 json.dump(out, open(f"profiles/{tag}_bench_counters.json", "w"), indent=1)
-shutil.copy(f"profiles/{tag}_bench_counters.json", "profiles/latest_bench_counters.json")
-print(open(f"profiles/{tag}_bench_kernel_stats.csv").read()[:1500])
+if len(sys.argv) <= 3:
+    shutil.copy(f"profiles/{tag}_bench_counters.json", "profiles/latest_bench_counters.json")
+print(open(f"profiles/{tag}_bench_kernel_stats.csv").read()[:1500] if os.path.exists(f"profiles/{tag}_bench_kernel_stats.csv") else "")
 print(json.dumps(out["per_kernel"], indent=1)[:3000])
 print(json.dumps(out["hcapped_per_kernel"], indent=1)[:2000])

@@ -21,3 +21,8 @@ SPATIAL_ORDER_STRATA = 32
 # inside the 1/30 s frame budget; fewer, larger strata keep 512-particle chunks more local on screen)
 MAX_PARTICLES_PER_STRATUM = 4_000_000
 SPATIAL_ORDER_MAX_STRATA = 400
+# Footprints at least this many pixels wide take kernel I (csrc/tsp_integrated.hip: second differences + two prefix sums of
+# the image) instead of the per-pixel kernels.  0 = off (the default: its result is exact to ~1e-6 of a footprint's PEAK
+# value, not of every pixel's own value -- tests/test_gpu_integrated.py); 256 takes a quarter off the frame time of a
+# 1e8-particle density render.  Must be 0 or >= 128.
+INTEGRATED_FOOTPRINT_PX = 0
