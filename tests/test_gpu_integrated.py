@@ -146,6 +146,33 @@ def test_through_the_visualizer(monkeypatch):
     assert np.abs(got - ref).max() <= 1e-5 * ref.max(), np.abs(got - ref).max() / ref.max()
 
 
+def test_on_several_contexts(native, mips):
+    """The option reaches every shard of the in-process multi-GPU driver (here two contexts on one device): the summed image
+    of a dense scene is within 1e-5 per pixel of one context's exact render."""
+    from topsy_amd import multigpu
+    R, scale, n = 512, 200.0, 3000000
+    M = np.eye(4, dtype=np.float32); M[:3, :3] /= scale; M[2, :] = [0, 0, 0.5 / scale, 0.5]
+    one = native.Context(R, 2)
+    one.set_kernel_mips(mips)
+    one.generate_synthetic(n, 0, n, 1337, 0.0)
+    one.render(M, 1.0 / scale)
+    exact = one.read_image()[..., 0].astype(np.float64)
+    one.close()
+    two = multigpu.MultiGpuContext(R, 2, [0, 0])
+    two.set_kernel_mips(mips)
+    two.generate_synthetic(n, 0, n, 1337, 0.0)
+    two.set_option("integrated_px", 128)
+    two.render(M, 1.0 / scale)
+    two.end_frame()
+    got = two.read_image()[..., 0].astype(np.float64)
+    assert two.stats()["n_mega"] > 1000
+    two.close()
+    lit = exact > 0
+    assert lit.mean() > 0.99
+    rel = np.abs(got - exact)[lit] / exact[lit]
+    assert rel.max() <= 1e-5, rel.max()
+
+
 def test_option_range(native, mips):
     ctx = native.Context(128, 2)
     ctx.set_kernel_mips(mips)
