@@ -18,20 +18,24 @@
 // scene (every pixel under thousands of such footprints) that is < 1e-6 relative per pixel; where a pixel holds only the
 // far tail of one footprint it is not within 1e-5 of the oracle.  tests/test_gpu_integrated.py states the contract.
 //
-// Layout: a workgroup owns a BAND of BH full image rows in LDS (float64, R x BH: 131 KB at 1024^2) and a share of the mega
-// records; per (footprint, band) its 64 lanes ARE the 64 x-breakpoints (column, two weights, computed once), and a scalar
-// loop walks the y-breakpoints whose two rows meet the band: one coalesced 528-byte row of S0, 6 multiplies and 4
-// ds_add_f64 per lane and y-breakpoint.  Breakpoints left of the viewport all land on columns 0 / 1: their sum is a linear
-// function of two prefix tables of S0 (PA, PB), formed by one lane -- no same-address pile-up.  The band is then added to the
-// global D2 image, and two small kernels integrate it twice along x and twice along y into the float64 render target.
+// Layout: a 1024-thread workgroup owns a TILE of BH image rows x <= 1024 columns in LDS (float64; 17 rows at 1024^2) plus a ghost
+// row / column on every side -- a breakpoint's two rows and two columns then always lie inside, and what falls on a ghost
+// cell is the neighbouring tile's to add -- and a share of the mega records.  Per (footprint, tile) its 64 lanes ARE the 64
+// x-breakpoints (column, two weights, computed once), and a scalar loop walks the y-breakpoints whose rows meet the band: one
+// coalesced 528-byte row of S0 (the next one already in flight), 6 multiplies and 4 ds_add_f64 per lane and y-breakpoint.
+// Breakpoints left of / above the viewport all land on columns / rows 0 and 1: their SUM is a linear function of prefix tables of
+// S0 (PA, PB along x; PAy, PBy along y; M for the corner), formed by one lane / one virtual breakpoint -- no same-address
+// pile-up, no 64-step walk in the top band.  The tile is then added to the global D2 image, and three small kernels integrate
+// it twice along x and twice along y into the float64 render target.  Several channels (weighted, depth, rgb): one pass each
+// (blockIdx.y), the channel's weight riding in the record's w.
 #include "tsp_pipeline.h"
 #include "tsp_math.h"
 
 namespace tsp {
 
-constexpr int IT = 1024;                 // threads per workgroup of kernel I (one workgroup per CU: the band fills its LDS)
+constexpr int IT = 1024;                 // threads per workgroup of kernel I (one workgroup per CU: the tile fills its LDS)
 constexpr int IWAVES = IT / 64;
-constexpr size_t INT_LDS_BYTES = 156 * 1024;   // LDS of a band: 17 + 2 rows of 1026 doubles at 1024^2, 7 + 2 rows at 2048^2
+constexpr size_t INT_LDS_BYTES = 156 * 1024;   // LDS of a tile: 17 + 2 rows of 1024 + 2 doubles (images wider than 1024 px are cut into column parts)
 
 struct IntArgs {
     const float4 *geom;
