@@ -93,6 +93,37 @@ def test_wide_footprints_against_the_oracle(native, mips, mode, R):
     ctx.close()
 
 
+@pytest.mark.parametrize("R", [300, 1024])
+def test_kernel_image_that_does_not_vanish_at_its_edges(native, mips, R):
+    """A level-0 image with values of 0.3 ... 0.9 on its edge rows and columns (and no symmetry): the jumps at the edges of the
+    footprint square -- ~1e-6 of the peak for the SPH kernel, below this file's tolerances -- then carry as much as the
+    interior.  Tolerance 5e-6 of the summed peaks: this image is rougher than the SPH kernel (the deviation is the texel-to-texel
+    difference times the ~1e-5 texel by which float32 texel coordinates are off)."""
+    from oracle import oracle_np
+    j, i = np.mgrid[0:64, 0:64].astype(np.float64)
+    custom = mips.copy()
+    custom[:4096] = (0.6 + 0.3 * np.sin(0.15 * i + 0.3) * np.cos(0.11 * j - 0.2)).astype(np.float32).ravel()
+    scale = 100.0
+    M, sf = oracle_np.transform_matrix(np.eye(3), np.zeros(3), scale)
+    pos, h, m, q, rgb = wide_scene(R, scale, 30, seed=R + 1)
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(custom)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+    ctx.upload_quantity(q)
+    ctx.set_option("integrated_px", 128)
+    ctx.set_option("count_fragments", 1)
+    ctx.render(M, sf)
+    got = ctx.read_image()
+    want, nfrag = oracle_render(pos, h, m, q, None, 0, M, sf, R, custom)
+    st = ctx.stats()
+    assert st["n_fragments"] == nfrag and st["n_mega"] == st["n_huge"] > 10
+    w0 = m.astype(np.float64) / h.astype(np.float64) ** 2
+    for c, sc in enumerate([float(w0.sum()), float((w0 * np.abs(q)).sum())]):
+        err = np.abs(got[..., c].astype(np.float64) - want[..., c])
+        assert err.max() <= 5e-6 * sc * 0.9, (c, err.max() / sc)
+    ctx.close()
+
+
 def test_dense_scene_is_within_the_relative_tolerance(native, mips):
     """4e6 synthetic particles at the reference camera: every pixel lies under hundreds of footprints >= 256 px, and the image
     with kernel I is within 1e-5 relative PER PIXEL of the exact kernels' (the north star's tolerance; measured ~1e-6 here and
