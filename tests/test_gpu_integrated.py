@@ -154,6 +154,44 @@ def test_dense_scene_is_within_the_relative_tolerance(native, mips):
     ctx.close()
 
 
+def test_reference_kats_with_kernel_I(native, mips, golden):
+    """The reference's own golden vectors (tests/test_render_output.py:161-241, 360-446) at ITS tolerances with every footprint
+    >= 128 px on kernel I: the scale-20 cameras of the weighted and bivariate vectors draw footprints of hundreds of pixels."""
+    kats = golden["reference_kats.npz"]
+    cams = golden["cameras.npz"]
+    d = golden["testdata_n1000.npz"]
+    ps, m, q = d["pos_smooth"], d["mass"], d["qty"]
+    ctx = native.Context(200, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(ps[:, 0], ps[:, 1], ps[:, 2], ps[:, 3], m)
+    ctx.set_option("integrated_px", 128)
+
+    def cam(name):
+        return cams[name + ".transform"].T.copy(), float(cams[name + ".scale_factor"][0])
+    M, sf = cam("identity_200")
+    ctx.render(M, sf)
+    test = ctx.read_image()[::20, ::20, 0].ravel()
+    expect = kats["test_sph_output.expect"]
+    np.testing.assert_allclose(test, expect, rtol=5e-1)           # reference :237
+    assert abs((test / expect).mean() - 1.0) < 0.0015             # reference :240
+    assert (test / expect).std() < 0.015                          # reference :241
+    ctx.upload_quantity(q)
+    M, sf = cam("rot0_0p4_20")
+    ctx.render(M, sf)
+    assert ctx.stats()["n_mega"] > 100
+    im = ctx.read_image()
+    np.testing.assert_allclose((im[..., 1] / im[..., 0])[::20, ::20].ravel(),
+                               kats["test_sph_weighted_output.expect"], atol=1.5e-7)   # reference :198
+    M, sf = cam("rot0_0p5_20")
+    ctx.render(M, sf)
+    assert ctx.stats()["n_mega"] > 100
+    im = ctx.read_image()
+    np.testing.assert_allclose(im[::20, ::20, 0].ravel(), kats["test_bivariate_render.expect_den"], rtol=2e-3)
+    np.testing.assert_allclose((im[..., 1] / im[..., 0])[::20, ::20].ravel(),
+                               kats["test_bivariate_render.expect_qty"], atol=1e-4)
+    ctx.close()
+
+
 def test_through_the_visualizer(monkeypatch):
     """config.INTEGRATED_FOOTPRINT_PX reaches the context of a Visualizer; the 1000-particle reference scene zoomed to
     scale 20 (footprints of hundreds of pixels at 200^2) against the default kernels."""
