@@ -1,9 +1,9 @@
-"""Prototype (numpy, float64) of the second-difference form of a bilinear footprint: the footprint's image is piecewise
+"""Model (numpy, float64; test infrastructure) of the second-difference form of a bilinear footprint: the footprint's image is piecewise
 bilinear in pixel coordinates, so its mixed second difference is sparse (4 entries per pair of texel breakpoints);
 scatter those, integrate twice along each axis.  Compares with the oracle's direct evaluation."""
 import sys, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import oracle_np as onp
 

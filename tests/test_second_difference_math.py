@@ -1,6 +1,6 @@
 """The mathematics of kernel I (csrc/tsp_integrated.hip) on the CPU: the mixed second difference of a bilinear footprint is
 sparse -- 4 entries per pair of texel breakpoints, strengths from one 66 x 66 table -- and two prefix sums along either axis give
-the footprint back.  numpy float64 model (tools/proto/second_difference.py) against the oracle's direct evaluation."""
+the footprint back.  numpy float64 model (tests/second_difference_model.py) against the oracle's direct evaluation."""
 import os
 import sys
 
@@ -8,14 +8,14 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools", "proto"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 f32 = np.float32
 
 
 @pytest.fixture(scope="module")
 def model():
-    import second_difference as sd
+    import second_difference_model as sd
     from oracle import oracle_np
     mips = oracle_np.kernel_mips()
     return sd, mips, sd.second_difference_table(mips[:4096].reshape(64, 64))
