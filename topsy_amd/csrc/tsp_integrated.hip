@@ -35,7 +35,10 @@ namespace tsp {
 
 constexpr int IT = 1024;                 // threads per workgroup of kernel I (one workgroup per CU: the tile fills its LDS)
 constexpr int IWAVES = IT / 64;
-constexpr size_t INT_LDS_BYTES = 156 * 1024;   // LDS of a tile: 17 + 2 rows of 1024 + 2 doubles (images wider than 1024 px are cut into column parts)
+#ifndef TSP_INT_LDS_KB
+#define TSP_INT_LDS_KB 156
+#endif
+constexpr size_t INT_LDS_BYTES = TSP_INT_LDS_KB * 1024;   // LDS of a tile: 17 + 2 rows of 1024 + 2 doubles (images wider than 1024 px are cut into column parts)
 
 struct IntArgs {
     const float4 *geom;
