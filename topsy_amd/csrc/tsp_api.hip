@@ -165,7 +165,7 @@ void tsp_destroy(tsp_context *ctx) {
     free_particles(ctx);
     void *ptrs[] = {ctx->image, ctx->image64, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->lut2d, ctx->scratch,
                     ctx->ws.mid_geom, ctx->ws.mid_w, ctx->ws.huge_geom, ctx->ws.huge_w, ctx->ws.seg_count, ctx->ws.seg_offset,
-                    ctx->ws.seg_bbox, ctx->ws.band_count, ctx->ws.band_list, ctx->ws.range_prefix, ctx->ws.count_diff, ctx->ws.count_band, ctx->ws.int_d2, ctx->ws.int_part, ctx->int_tables, ctx->sort_keys, ctx->sort_keys_alt, ctx->sort_tmp};
+                    ctx->ws.seg_bbox, ctx->ws.band_count, ctx->ws.band_list, ctx->ws.range_prefix, ctx->ws.count_diff, ctx->ws.count_band, ctx->ws.int_d2, ctx->ws.int_part, ctx->ws.int_wmax, ctx->int_tables, ctx->sort_keys, ctx->sort_keys_alt, ctx->sort_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &e : ctx->ev)
@@ -207,6 +207,8 @@ int tsp_set_kernel_mips(tsp_context *ctx, const float *lut, int n0, int n_levels
         std::vector<double> tables;
         integrated_tables(lut, tables);
         ctx->int_edge[0] = ctx->int_edge[1] = 0;
+        ctx->int_peak = 0.0f;
+        for (int i = 0; i < 64 * 64; ++i) ctx->int_peak = std::max(ctx->int_peak, fabsf(lut[i]));
         for (int q = 0; q < 66; ++q)
             if (tables[(size_t)q * INT_S0_STRIDE] != 0.0 || tables[(size_t)q * INT_S0_STRIDE + 65] != 0.0) ctx->int_edge[q >> 6] |= 1ull << (q & 63);
         if (!ctx->int_tables) TSP_HIP(hipMalloc((void **)&ctx->int_tables, tables.size() * sizeof(double)));

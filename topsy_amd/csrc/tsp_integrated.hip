@@ -14,7 +14,8 @@
 // What it gives up (why it is an option, not the default): the adds cancel to the footprint's values only up to float64
 // rounding, and the texel coordinates are exact instead of the float32-rounded ones of the canonical arithmetic
 // (tsp_math.h), so a pixel differs from the oracle by ~1e-7 of the footprint's PEAK value (not of the pixel's own value),
-// and pixels a footprint does not touch receive ~1e-10 of its peak instead of exactly 0 (possibly negative).  In a dense
+// and what the adds leave where a footprint draws nothing is ~1e-10 of its peak, of either sign (the last prefix-sum kernel snaps
+// everything below 1e-8 of the pass's largest peak contribution to the exact zero it stands for).  In a dense
 // scene (every pixel under thousands of such footprints) that is < 1e-6 relative per pixel; where a pixel holds only the
 // far tail of one footprint it is not within 1e-5 of the oracle.  tests/test_gpu_integrated.py states the contract.
 //
@@ -48,6 +49,7 @@ struct IntArgs {
     const double *T;                     // the breakpoint tables (integrated_tables)
     unsigned long long edge_lo, edge_hi; // bit q (of 66): row q of S0 has a non-zero edge jump (S0[q][0] or S0[q][65])
     double *D2;                          // [channels][R][R] second-difference images (blockIdx.y = channel)
+    unsigned int *wmax;                  // [channels] largest |weight| of the pass (float bits): scales the zero threshold of the prefix sums
     Counters *cnt;
     int R, BH, STR, TW, nx, split, count_frag;   // tile = BH rows x TW columns (nx column parts per band), LDS row stride STR = TW + 2
     float p_lo;                          // records narrower than this belong to the matrix-core kernels
@@ -77,6 +79,7 @@ __global__ __launch_bounds__(IT) void splat_integrated_kernel(IntArgs a) {
     __syncthreads();
     unsigned long long n_frag = 0;
     bool touched = false;
+    float wmax = 0.0f;
 
     // the workgroup's share of the records is dealt to its waves in runs of HDEAL, like the tile-gather kernels
     const long long vsplit = (long long)a.split * IWAVES, vsp = (long long)sp * IWAVES + wv;
@@ -93,6 +96,7 @@ __global__ __launch_bounds__(IT) void splat_integrated_kernel(IntArgs a) {
         int ilo = 1, ihi = 0, jlo = 1, jhi = 0;
         bool hit = false;
         if (g.z >= a.p_lo && g.z > 0.0f) {
+            wmax = fmaxf(wmax, __builtin_fabsf(g.w));
             const float hf = 0.5f * g.z;
             cover_range(g.x, hf, R, ilo, ihi);
             cover_range(g.y, hf, R, jlo, jhi);
@@ -254,6 +258,10 @@ __global__ __launch_bounds__(IT) void splat_integrated_kernel(IntArgs a) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
         if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
     }
+    if (tile_id == 0) {      // (every tile sees every record: one of them reports)
+        for (int o = 32; o; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+        if (lane == 0 && wmax > 0.0f) atomicMax(&a.wmax[ch], __float_as_uint(wmax));     // non-negative floats order like their bits
+    }
 }
 
 // ---- the double prefix sums -------------------------------------------------------------------------------------------------
@@ -299,13 +307,18 @@ __global__ __launch_bounds__(256) void integrate_cols_partial_kernel(const doubl
     part[(size_t)seg * R + i] = make_double2(r1, r2);
 }
 // pass 2: carry in the segments above, finish, add into the channel of the render target and clear D2 for the next block
+// What is left of the cancelling adds where no footprint (or only its exactly-zero corner) reaches is ~1e-10 of a peak
+// contribution, of either sign: values below 1e-8 of the pass's largest peak contribution count as the exact zero they stand for
+// (no negative dust in a density image: the reference's autorange picks the linear scale on ANY negative value).
 __global__ __launch_bounds__(256) void integrate_cols_apply_kernel(double *__restrict__ D2, int R, const double2 *__restrict__ part,
-                                                                   double *__restrict__ img, int C) {
+                                                                   double *__restrict__ img, int C, const unsigned int *__restrict__ wmax,
+                                                                   float peak) {
     const int i = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y;
     if (i >= R) return;
     D2 += (size_t)blockIdx.z * R * R;
     part += (size_t)blockIdx.z * gridDim.y * R;
     img += blockIdx.z;                       // channel c of the render target
+    const double thr = 1e-8 * (double)peak * (double)__uint_as_float(wmax[blockIdx.z]);
     double c1 = 0.0, c2 = 0.0;
     for (int s = 0; s < seg; ++s) {
         const double2 p = part[(size_t)s * R + i];
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(256) void integrate_cols_apply_kernel(double *__res
         const size_t k = (size_t)j * R + i;
         c1 += D2[k]; c2 += c1;
         D2[k] = 0.0;
-        if (c2 != 0.0) gatomic_add(img + k * C, c2);
+        if (__builtin_fabs(c2) > thr) gatomic_add(img + k * C, c2);
     }
 }
 
@@ -342,10 +355,12 @@ int launch_integrated(tsp_context *ctx, const TileArgs &ta, const float4 *geom, 
         TSP_HIP(hipMemsetAsync(ws.int_d2, 0, (size_t)nch * R * R * sizeof(double), st));
         ws.int_channels = nch;
     }
+    if (!ws.int_wmax) TSP_HIP(hipMalloc((void **)&ws.int_wmax, 4 * sizeof(unsigned int)));
+    TSP_HIP(hipMemsetAsync(ws.int_wmax, 0, 4 * sizeof(unsigned int), st));
     IntArgs ia;
     ia.geom = geom; ia.wq = wq; ia.wmode = wmode; ia.n_records = n_records;
     ia.T = ctx->int_tables; ia.p_lo = p_lo;
-    ia.D2 = ws.int_d2; ia.cnt = ta.cnt; ia.R = R; ia.count_frag = ta.count_frag;
+    ia.D2 = ws.int_d2; ia.wmax = ws.int_wmax; ia.cnt = ta.cnt; ia.R = R; ia.count_frag = ta.count_frag;
     // tiles of at most 1024 columns (+ a ghost column either side): 17 rows of them fit the LDS, and a footprint meets P / 17 + 1 bands
     ia.nx = (R + 1023) / 1024;
     ia.TW = (R + ia.nx - 1) / ia.nx;
@@ -370,7 +385,7 @@ int launch_integrated(tsp_context *ctx, const TileArgs &ta, const float4 *geom, 
     hipLaunchKernelGGL(integrate_rows_kernel, dim3(R, nch), dim3(256), 0, st, ws.int_d2, R);
     hipLaunchKernelGGL(integrate_cols_partial_kernel, dim3((R + 255) / 256, nseg, nch), dim3(256), 0, st, ws.int_d2, R, (double2 *)ws.int_part);
     hipLaunchKernelGGL(integrate_cols_apply_kernel, dim3((R + 255) / 256, nseg, nch), dim3(256), 0, st, ws.int_d2, R, (const double2 *)ws.int_part,
-                       ctx->image64, ctx->C);
+                       ctx->image64, ctx->C, ws.int_wmax, ctx->int_peak);
     TSP_HIP(hipGetLastError());
     return TSP_OK;
 }

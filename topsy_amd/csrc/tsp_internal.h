@@ -71,6 +71,7 @@ struct Workspace {     // per-context scratch of the three-class pipeline (grown
     int *count_band = nullptr;          // rgb: per (64-row band, column) sums of its row-scanned form
     double *int_d2 = nullptr;           // kernel I: [int_channels] R x R second-difference images (zero between render blocks)
     int int_channels = 0;
+    unsigned int *int_wmax = nullptr;   // kernel I: per channel, the largest |weight| of the pass (float bits)
     void *int_part = nullptr;           // kernel I: per (32-row segment, column) partial sums of the column pass
 };
 
@@ -118,6 +119,7 @@ struct tsp_context {
     float p_mega2 = 256.0f;           // the same for two-channel renders (weighted, depth): their H2 pays 5 instead of 2 FMAs per pixel row
     float p_mega_rgb = 128.0f;        // ... and for rgb (kernel H below, kernel H3 with three accumulator sets above)
     float integrated_px = 0.0f;       // option: density footprints at least this wide (>= 128) go through kernel I (second differences + prefix sums, tsp_integrated.hip); 0 = off
+    float int_peak = 0.0f;            // kernel I: largest level-0 texel
     unsigned long long int_edge[2] = {0, 0};   // kernel I: rows of S0 with a non-zero edge jump (bit q of 66)
     double *int_tables = nullptr;     // kernel I: breakpoint strengths of the level-0 kernel image and their prefix sums (integrated_tables)
     int mega_variant = 0;             // density: 0 = auto, 1 = kernel H3 on 64 x 32 strips, 2 / 3 = on 64 x 64 strips at 4 / 3 waves per SIMD
