@@ -62,7 +62,10 @@ enum {
 const char *tsp_last_error(void);
 /* ABI version.  100: first release.  101: tsp_stats grew by 16 bytes (ms_mega, n_mega appended) -- tsp_get_stats
  * writes sizeof(tsp_stats) bytes, so a client compiled against the version-100 header must not be run against a
- * version-101 library (check tsp_version() >= 101 and tsp_stats_size() == sizeof(tsp_stats) at start-up). */
+ * version-101 library (check tsp_version() >= 101 and tsp_stats_size() == sizeof(tsp_stats) at start-up).  The same
+ * release narrowed the option "p_small_milli" from <= 22627 to <= 16000 (kernel S packs at most 16 texel columns per
+ * footprint; the default moved from 13.5 to 16 px): values 16001..22627 now return TSP_EINVAL.
+ * 102: tsp_stats grew by 32 bytes (n_fragments_stream / _mid / _huge / _mega appended); same rule. */
 int tsp_version(void);
 int tsp_stats_size(void);
 
@@ -221,6 +224,9 @@ typedef struct {
     double ms_stream, ms_mid, ms_huge, ms_total; /* per-kernel GPU time, hipEvents; ms_huge = kernel H or H2 */
     double ms_mega;        /* kernel H3 (footprints >= p_mega px on the matrix cores); 0 when it did not run */
     int64_t n_mega;        /* footprints handled by kernel H3 */
+    /* n_fragments by the kernel that drew them (counted like n_fragments; 0 on the generic pipeline): kernel S, kernel M,
+     * kernel H / H2, kernel H3 (or kernel I) -- what bench.py prices each kernel's fragment-rate roofline with */
+    int64_t n_fragments_stream, n_fragments_mid, n_fragments_huge, n_fragments_mega;
 } tsp_stats;
 int tsp_get_stats(tsp_context *ctx, tsp_stats *out);
 /* Options by name.  "count_fragments" (0/1): fragment counting (adds atomics; off by default).  "integrated_px" (0 = off, the

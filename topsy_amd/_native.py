@@ -16,7 +16,7 @@ MODE_WEIGHTED, MODE_DEPTH, MODE_RGB = 0, 1, 2
 PIPE_DEFAULT, PIPE_GENERIC = 0, 1
 SAMPLE_BILINEAR_MIP0, SAMPLE_BILINEAR_MIP = 0x10, 0x20      # diagnostic sampling rules (generic kernel)
 UNIQUE_ID_BYTES = 128
-ABI_VERSION = 101            # include/topsy_splat.h: tsp_version()
+ABI_VERSION = 102            # include/topsy_splat.h: tsp_version()
 
 
 class BackendUnavailable(RuntimeError):
@@ -31,7 +31,9 @@ class Stats(ctypes.Structure):
     _fields_ = [("n_particles", ctypes.c_int64), ("n_small", ctypes.c_int64), ("n_mid", ctypes.c_int64),
                 ("n_huge", ctypes.c_int64), ("n_culled", ctypes.c_int64), ("n_fragments", ctypes.c_int64),
                 ("ms_stream", ctypes.c_double), ("ms_mid", ctypes.c_double), ("ms_huge", ctypes.c_double),
-                ("ms_total", ctypes.c_double), ("ms_mega", ctypes.c_double), ("n_mega", ctypes.c_int64)]
+                ("ms_total", ctypes.c_double), ("ms_mega", ctypes.c_double), ("n_mega", ctypes.c_int64),
+                ("n_fragments_stream", ctypes.c_int64), ("n_fragments_mid", ctypes.c_int64),
+                ("n_fragments_huge", ctypes.c_int64), ("n_fragments_mega", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -263,6 +265,11 @@ class Context:
             l = np.ascontiguousarray(lens, dtype=np.int64)
             if s.shape != l.shape or s.ndim != 1:
                 raise ValueError("starts and lens must be 1-D arrays of equal length")
+            if len(s) == 0:
+                # an empty selection (e.g. view culling picked no cell of this block) draws nothing: hand the library one
+                # explicit zero-length range so that it can never be read as "no ranges given = all particles"
+                s = np.zeros(1, dtype=np.int64)
+                l = np.zeros(1, dtype=np.int64)
             sp, lp, nr = s.ctypes.data_as(_i64p), l.ctypes.data_as(_i64p), len(s)
         _check(self._lib.tsp_render(self._h, _ptr(M), float(scale_factor), sp, lp, nr, int(bool(clear)), int(mode),
                                     int(flags), ctypes.byref(ms)))

@@ -97,7 +97,7 @@ using namespace tsp;
 extern "C" {
 
 const char *tsp_last_error(void) { return g_err; }
-int tsp_version(void) { return 101; }     // 101: tsp_stats gained ms_mega, n_mega (16 bytes)
+int tsp_version(void) { return 102; }     // 101: tsp_stats gained ms_mega, n_mega (16 bytes); 102: the per-kernel fragment counts (32 bytes)
 int tsp_stats_size(void) { return (int)sizeof(tsp_stats); }
 
 int tsp_device_count(void) {
@@ -469,6 +469,10 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
     ctx->stats.n_mega = (int64_t)hc.n_mega;
     ctx->stats.n_culled = (int64_t)hc.n_culled;
     ctx->stats.n_fragments = (int64_t)hc.n_fragments;
+    ctx->stats.n_fragments_stream = (int64_t)hc.n_frag_class[0];
+    ctx->stats.n_fragments_mid = (int64_t)hc.n_frag_class[1];
+    ctx->stats.n_fragments_huge = (int64_t)hc.n_frag_class[2];
+    ctx->stats.n_fragments_mega = (int64_t)hc.n_frag_class[3];
     if (gpu_ms_out) *gpu_ms_out = ms;
     return TSP_OK;
 }

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(HT, (NACC == 3) ? TSP_H_OCC3 : 4) void splat_huge_k
     }
     if (a.count_frag) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
-        if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+        if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[2], n_frag); }
     }
 }
 
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     }
     if (a.count_frag) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
-        if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+        if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[2], n_frag); }
     }
 }
 
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
     flush();
     if (a.count_frag) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
-        if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+        if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[3], n_frag); }
     }
 }
 
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega64_kernel(TileArgs a) {
     flush();
     if (a.count_frag) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
-        if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+        if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[3], n_frag); }
     }
 }
 
@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_tile4_kernel(TileArgs a) {
     flush();
     if (a.count_frag) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
-        if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+        if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[2], n_frag); }
     }
 }
 

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(IT) void splat_integrated_kernel(IntArgs a) {
     }
     if (a.count_frag) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
-        if (lane == 0 && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+        if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[3], n_frag); }
     }
     if (tile_id == 0) {      // (every tile sees every record: one of them reports)
         for (int o = 32; o; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));

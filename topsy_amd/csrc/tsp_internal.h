@@ -51,6 +51,7 @@ struct Record4 {   // rgb variant (24 B)
 
 struct Counters {      // device-side, zeroed per render call
     unsigned long long n_small, n_mid, n_huge, n_culled, n_fragments, huge_count, n_mega, pad1;
+    unsigned long long n_frag_class[4];   // n_fragments by the kernel that drew them: S, M, H / H2, H3 / I
 };
 
 struct Workspace {     // per-context scratch of the three-class pipeline (grown on demand)

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
     if (lane == 0) {
         if (n_small) atomicAdd(&a.cnt->n_small, n_small);
         if (n_cull) atomicAdd(&a.cnt->n_culled, n_cull);
-        if (n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+        if (n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[0], n_frag); }
     }
 }
 
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
             }
         }
     }
-    if (a.count_frag && n_frag) atomicAdd(&a.cnt->n_fragments, n_frag);
+    if (a.count_frag && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[1], n_frag); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -931,6 +931,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     if (carry.n_small || carry.n_fragments) {   // statistics of the first attempt (its small footprints stand)
         hc.n_small += carry.n_small;
         hc.n_fragments += carry.n_fragments;
+        hc.n_frag_class[0] += carry.n_frag_class[0];
         TSP_HIP(hipMemcpyAsync(ctx->counters, &hc, sizeof(hc), hipMemcpyHostToDevice, st));
         TSP_HIP(hipStreamSynchronize(st));
     }
