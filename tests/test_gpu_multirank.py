@@ -170,3 +170,40 @@ def test_rgb_and_depth_on_several_contexts_of_one_device():
         outs.append(v.get_sph_image().copy())
         v.close()
     assert np.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-30)
+
+
+def test_interleaved_shards_balance_a_cell_sorted_snapshot():
+    """A loader with its own cell layout hands the particles over sorted by spatial cell (reference loader.py:88-97): contiguous
+    index-range shards are then spatial slabs -- the dense core on one GPU, the fragment-heavy outskirts on others.  The
+    block-cyclic assignment ('interleaved', what 'auto' picks for such loaders) gives every shard the same mix: per-shard GPU
+    time max / mean <= 1.3, the image equal to the one-context image at 1e-5.  The four contexts share device 0 here, so
+    the shards render ONE AFTER ANOTHER for clean per-shard timings (a one-thread pool); split arithmetic preserved:
+    split_buffers.py:78-116."""
+    from concurrent.futures import ThreadPoolExecutor
+    import topsy_amd
+    from topsy_amd.drawreason import DrawReason
+    n, R = 4_000_000, 1024
+    one = topsy_amd.test(n, render_resolution=R, with_cells=True)
+    one.scale = 200.0
+    one.render_sph(DrawReason.EXPORT)
+    want = one._sph.get_image().copy()
+    one.close()
+    ratios = {}
+    for assignment in ("contiguous", "interleaved", None):
+        v = topsy_amd.test(n, render_resolution=R, with_cells=True, device_ids=[0, 0, 0, 0], shard_assignment=assignment)
+        ctx = v.particle_buffers.context
+        assert ctx.assignment == (assignment or "interleaved")          # None = config 'auto' = interleaved for a cell-sorted loader
+        ctx._pool = ThreadPoolExecutor(max_workers=1)                   # sequential shards: timings do not disturb each other
+        v.scale = 200.0
+        best = None
+        for _ in range(3):
+            v.render_sph(DrawReason.EXPORT)
+            ms = np.array([s["ms_total"] for s in ctx.per_shard_stats()])
+            best = ms if best is None else np.minimum(best, ms)
+        got = v._sph.get_image().copy()
+        assert np.allclose(got[..., 0], want[..., 0], rtol=1e-5, atol=0), assignment
+        ratios[assignment or "auto"] = float(best.max() / best.mean())
+        v.close()
+    print("per-shard ms_total max/mean:", ratios)
+    assert ratios["interleaved"] <= 1.3 and ratios["auto"] <= 1.3
+    assert ratios["contiguous"] > ratios["interleaved"], "the cell-sorted input is what the interleaved assignment is for"

@@ -114,6 +114,13 @@ class FakeContext:
     def stats(self):
         return {"n_particles": 0, "ms_total": 1.0}
 
+    def download_particles(self, names=("x", "y", "z", "h", "mass")):
+        src = {"x": self.x, "y": self.y, "z": self.z, "h": self.h, "mass": self.m, "q": self.q}
+        return {k: src[k].copy() for k in names}
+
+    def comm_destroy(self):
+        self.comm_destroyed = True
+
     def close(self):
         pass
 
@@ -226,3 +233,75 @@ def test_multi_context_block_boundaries_and_ranges(fake_backend):
     assert (r[1][0].tolist(), r[1][1].tolist()) == ([0, 327], [67, 6])
     assert (r[2][0].tolist(), r[2][1].tolist()) == ([0], [4])
     ctx.close()
+
+
+def test_interleaved_assignment_index_maps(fake_backend):
+    """Block-cyclic shards: every shard's global -> local index map is monotone, so a global (start, len) range is ONE local
+    range per shard (what global_to_split_monotonic needs of a split, split_buffers.py:78-116), the shards partition every
+    range, and uploads / downloads / quantity swaps address the same particles."""
+    from topsy_amd import multigpu
+    n, B, G = 10_037, 64, 3
+    ctx = multigpu.MultiGpuContext(32, 4, [0, 1, 2], assignment="interleaved", interleave_block=B)
+    rs = np.random.RandomState(5)
+    x = np.arange(n, dtype=np.float32)                       # x = the particle's global index
+    ctx.set_kernel_mips(np.zeros(5440, dtype=np.float32))
+    ctx.upload_particles(x, x, x, np.ones(n, np.float32), np.ones(n, np.float32))
+    assert ctx.num_particles == n and sum(c.n for c in ctx.contexts) == n
+    for g, c in enumerate(ctx.contexts):
+        own = c.x.astype(np.int64)
+        assert (np.diff(own) > 0).all() and ((own // B) % G == g).all()
+        assert max(abs(c.n - n / G) for c in ctx.contexts) <= B
+    q = rs.normal(size=n).astype(np.float32)
+    ctx.upload_quantity(q)
+    for c in ctx.contexts:
+        assert np.array_equal(c.q, q[c.x.astype(np.int64)])
+    back = ctx.download_particles(("x", "q"))
+    assert np.array_equal(back["x"], x) and np.array_equal(back["q"], q)
+    for _ in range(50):
+        k = rs.randint(1, 6)
+        starts = np.sort(rs.randint(0, n, size=k)).astype(np.int64)
+        lens = rs.randint(0, 700, size=k).astype(np.int64)
+        lens = np.minimum(lens, n - starts)
+        ctx.render(np.eye(4, dtype=np.float32), 1.0, starts, lens, clear=True)
+        drawn = []
+        for c in ctx.contexts:
+            ls, ll = c.last_ranges
+            assert len(ls) <= k
+            for a, b in zip(ls, ll):
+                drawn.append(c.x[a:a + b].astype(np.int64))
+        drawn = np.sort(np.concatenate(drawn)) if drawn else np.empty(0, dtype=np.int64)
+        want = np.sort(np.concatenate([np.arange(a, a + b) for a, b in zip(starts, lens)] + [np.empty(0, dtype=np.int64)]))
+        assert np.array_equal(drawn, want)
+    # after a library reordering the index space is the concatenation of the shards; the permutation maps back to the caller's order
+    perm = ctx.reorder_spatial(6, 1, want_permutation=True)
+    assert np.array_equal(np.sort(perm), np.arange(n))
+    assert np.array_equal(perm, np.concatenate([c.x.astype(np.int64) for c in ctx.contexts]))
+    ctx.render(np.eye(4, dtype=np.float32), 1.0, [0], [ctx.contexts[0].n], clear=True)
+    r = [c.last_ranges for c in ctx.contexts]
+    assert r[0][1].sum() == ctx.contexts[0].n and r[1][1].sum() == 0 and r[2][1].sum() == 0
+    q2 = rs.normal(size=n).astype(np.float32)
+    ctx.upload_quantity(q2)                                   # still given in the caller's order
+    for c in ctx.contexts:
+        assert np.array_equal(c.q, q2[c.x.astype(np.int64)])
+    ctx.close()
+    assert all(getattr(c, "comm_destroyed", False) for c in ctx.contexts)
+    with pytest.raises(AttributeError):
+        ctx.write_image                                        # root-only mutations are not forwarded
+
+
+def test_cell_sorted_loader_is_sharded_interleaved_and_renders_the_same_image(fake_backend):
+    """A loader with its own cell layout hands over spatially sorted particles (reference loader.py:88-97): 'auto' deals them
+    block-cyclically, the cell progression's (start, len) ranges reach every shard, and the frame equals the one-context frame."""
+    from topsy_amd import multigpu
+    from topsy_amd.drawreason import DrawReason
+    n, R = 30_000, 64
+    one = _Vis(n, R, None, with_cells=True)
+    want = _frame(one, DrawReason.EXPORT, R).get_image()
+    many = _Vis(n, R, [0, 1, 2, 3], with_cells=True)
+    ctx = many.particle_buffers.context
+    assert isinstance(ctx, multigpu.MultiGpuContext) and ctx.assignment == "interleaved"
+    assert max(c.n for c in ctx.contexts) - min(c.n for c in ctx.contexts) <= ctx.interleave_block
+    got = _frame(many, DrawReason.EXPORT, R).get_image()
+    np.testing.assert_allclose(got[..., 0], want[..., 0], rtol=1e-5, atol=0)
+    plain = _Vis(n, R, [0, 1, 2, 3], with_cells=False)
+    assert plain.particle_buffers.context.assignment == "contiguous"

@@ -403,6 +403,10 @@ class Context:
             raise ValueError("unique id must be 128 bytes")
         _check(self._lib.tsp_comm_init(self._h, n_ranks, rank, unique_id))
 
+    def comm_destroy(self):
+        if getattr(self, "_h", None):
+            _check(self._lib.tsp_comm_destroy(self._h))
+
     def comm_reduce_image(self, root=0):
         ms = ctypes.c_double(0.0)
         _check(self._lib.tsp_comm_reduce_image(self._h, root, ctypes.byref(ms)))

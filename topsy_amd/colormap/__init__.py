@@ -81,6 +81,37 @@ class ColormapHolder:
         self._check_valid()
         return self._impl.sph_raw_output_to_content(sph_raw_output)
 
+    def colormap_kind(self):
+        """'bivariate' | 'rgb' | 'scalar': the family of the active implementation (what the reference's
+        make_ui_controller dispatches on, src/topsy/colormap/__init__.py:131-147; 'surface' is out of scope here)."""
+        self._check_valid()
+        if isinstance(self._impl, BivariateColormap):
+            return "bivariate"
+        if isinstance(self._impl, RGBColormap):
+            return "rgb"
+        return "scalar"
+
+    def make_ui_controller(self, visualizer, refresh_ui_callback=None, controller_classes=None):
+        """The UI controller for the active colormap (reference src/topsy/colormap/__init__.py:131-147).
+
+        The controllers themselves are UI (reference src/topsy/colormap/ui.py: Qt / Jupyter widget descriptions) and out of
+        this backend's scope, so they are taken from the caller: `controller_classes` maps 'bivariate' / 'rgb' / 'scalar' to
+        a GenericController subclass; when omitted, the reference's own classes are used if topsy is importable (the
+        maintainer's integration).  They only need what this holder offers: get_parameter(s),
+        update_parameters and [] access."""
+        kind = self.colormap_kind()
+        if controller_classes is None:
+            try:
+                from topsy.colormap import ui as ref_ui
+            except ImportError as e:
+                raise NotImplementedError(
+                    "make_ui_controller needs the UI controller classes of topsy's colormap/ui.py (BivariateColorMapController, "
+                    "RGBMapController, ColorMapController); pass them as controller_classes={'bivariate': ..., 'rgb': ..., "
+                    "'scalar': ...} or make the `topsy` package importable") from e
+            controller_classes = {"bivariate": ref_ui.BivariateColorMapController, "rgb": ref_ui.RGBMapController,
+                                  "scalar": ref_ui.ColorMapController}
+        return controller_classes[kind](visualizer, refresh_ui_callback)
+
     def __getitem__(self, key):
         return self.get_parameter(key)
 

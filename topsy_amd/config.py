@@ -26,3 +26,9 @@ SPATIAL_ORDER_MAX_STRATA = 400
 # value, not of every pixel's own value -- tests/test_gpu_integrated.py); 256 takes a quarter off the frame time of a
 # 1e8-particle density render.  Must be 0 or >= 128.
 INTEGRATED_FOOTPRINT_PX = 0
+# Several GPUs behind one Visualizer (multigpu.py): how the caller's particle order is cut into shards.  "contiguous" =
+# index ranges [g N / G, (g + 1) N / G) (split_buffers.py:26-38); "interleaved" = blocks of MULTI_GPU_INTERLEAVE_BLOCK
+# consecutive particles dealt to the shards in turn; "auto" = interleaved when the loader brings its own cell layout (its
+# order is then spatially sorted and index ranges are spatial slabs of very different cost), contiguous otherwise.
+MULTI_GPU_SHARD_ASSIGNMENT = "auto"
+MULTI_GPU_INTERLEAVE_BLOCK = 4096

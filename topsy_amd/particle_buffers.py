@@ -18,7 +18,8 @@ _UNSET = object()
 
 
 class ParticleBuffers:
-    def __init__(self, loader, resolution, device_id=0, max_draw_calls_per_buffer=1, device_ids=None):
+    def __init__(self, loader, resolution, device_id=0, max_draw_calls_per_buffer=1, device_ids=None,
+                 shard_assignment=None):
         self._loader = loader
         self.quantity_name = None
         self._quantity_on_device = _UNSET
@@ -32,7 +33,11 @@ class ParticleBuffers:
         # sharded by index range and the image summed once per frame (multigpu.py)
         if device_ids is not None and len(device_ids) > 1:
             from . import multigpu
-            self.context = multigpu.MultiGpuContext(resolution, 4, device_ids)
+            assignment = shard_assignment or config.MULTI_GPU_SHARD_ASSIGNMENT
+            if assignment == "auto":
+                assignment = "interleaved" if hasattr(loader, "_cell_layout") else "contiguous"
+            self.context = multigpu.MultiGpuContext(resolution, 4, device_ids, assignment=assignment,
+                                                    interleave_block=config.MULTI_GPU_INTERLEAVE_BLOCK)
         else:
             self.context = _native.Context(resolution, 4, device_id if not device_ids else device_ids[0])
         self.context.set_kernel_mips(kernel_lut.kernel_mips())

@@ -28,10 +28,11 @@ class VisualizerBase:
     def __init__(self, data_loader_class=loader.TestDataLoader, data_loader_args=(), data_loader_kwargs={},
                  *, render_resolution=config.DEFAULT_RESOLUTION, periodic_tiling=False,
                  colormap_name=config.DEFAULT_COLORMAP, canvas_class=None, render_mode="univariate", device_id=0,
-                 n_gpus=None, device_ids=None):
+                 n_gpus=None, device_ids=None, shard_assignment=None):
         """n_gpus / device_ids: render on several GPUs of this node from this one process -- the particles are sharded
         by index range, every render block runs on all shards at once and the frame ends with one RCCL sum-reduce of the
-        image onto the first device (topsy_amd/multigpu.py); everything else (colormap, autorange, exports) is unchanged."""
+        image onto the first device (topsy_amd/multigpu.py); everything else (colormap, autorange, exports) is unchanged.
+        shard_assignment: "contiguous" | "interleaved" | "auto" (config.MULTI_GPU_SHARD_ASSIGNMENT)."""
         self._render_resolution = render_resolution
         self._sph = None
         self._colormap = None
@@ -45,7 +46,8 @@ class VisualizerBase:
         self.data_loader = data_loader_class(self.device, *data_loader_args, **data_loader_kwargs)
         self.particle_buffers = particle_buffers.ParticleBuffers(
             self.data_loader, render_resolution, self._device_id,
-            self.data_loader.get_render_progression().get_max_particle_regions_per_block(), device_ids=device_ids)
+            self.data_loader.get_render_progression().get_max_particle_regions_per_block(), device_ids=device_ids,
+            shard_assignment=shard_assignment)
         self.periodicity_scale = self.data_loader.get_periodicity_scale()
         self._periodic_tiling = periodic_tiling
         if periodic_tiling and not self.periodicity_scale:
