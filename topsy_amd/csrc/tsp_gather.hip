@@ -104,13 +104,14 @@ __global__ __launch_bounds__(HT, (NACC == 3) ? TSP_H_OCC3 : 4) void splat_huge_k
     // Records are dealt to the `split` workgroups of a tile in runs of HDEAL: consecutive records are spatial
     // neighbours (they come from consecutive chunks), so a workgroup's batch of 256 is made of 256 / HDEAL runs
     // taken `split` runs apart -- every workgroup sees an even sample of the tile's footprints
-    const long long n_runs = (a.n_records + HDEAL - 1) / HDEAL;
-    for (long long run0 = 0; run0 * a.split < n_runs; run0 += 256 / HDEAL) {
+    // (32-bit record indices: the launcher refuses lists of 2^31 records or more)
+    const unsigned n_rec = (unsigned)a.n_records, n_runs = (n_rec + HDEAL - 1) / HDEAL, usplit = (unsigned)a.split;
+    for (unsigned run0 = 0; run0 * usplit < n_runs; run0 += 256 / HDEAL) {
         // ---- waves 0-3 test 256 records against the tile and compact the hits into the LDS queue ----
-        const long long ri = ((run0 + (tid & 255) / HDEAL) * a.split + sp) * HDEAL + (tid & (HDEAL - 1));
+        const unsigned ri = ((run0 + (tid & 255) / HDEAL) * usplit + sp) * HDEAL + (tid & (HDEAL - 1));
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         bool hit = false;
-        if (tid < 256 && ri < a.n_records) {
+        if (tid < 256 && ri < n_rec) {
             g = a.geom[ri];
             const float half = 0.5f * g.z;
             hit = (g.x + half > fx0) && (g.x - half < fx1) && (g.y + half > fy0) && (g.y - half < fy1);
@@ -210,32 +211,42 @@ __global__ __launch_bounds__(HT, (NACC == 3) ? TSP_H_OCC3 : 4) void splat_huge_k
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (a.count_frag) n_frag += (unsigned long long)(ncov_x * ncov_y);
-            // fold the short-run accumulators into the totals every 64 footprints: bounds the
-            // float32 accumulation error at ~sqrt(64)*2^-24 per level instead of sqrt(n)
-            if (++since_fold == FOLD_EVERY) {
-                since_fold = 0;
-                if (REG_TOTALS) {
+            if (REG_TOTALS) {
+                // fold the short-run accumulators into the totals every 64 footprints: bounds the
+                // float32 accumulation error at ~sqrt(64)*2^-24 per level instead of sqrt(n)
+                if (++since_fold == FOLD_EVERY) {
+                    since_fold = 0;
 #pragma unroll
                     for (int p = 0; p < NPX; ++p)
 #pragma unroll
                         for (int c = 0; c < NACC; ++c) { tot[p < NTOT ? p : 0][c] += acc[p][c]; acc[p][c] = 0.0f; }
-                } else {
+                }
+            }
+        }
+        if (!REG_TOTALS) {
+            // no register totals (rgb): the accumulators go to the float64 target once they may hold FOLD_EVERY footprints
+            // (<= FOLD_EVERY + 255: counted per 256-record batch) -- HERE, between the batches, not under the footprint loop,
+            // where the 48 conditional atomics and their addresses cost the hot loop 300 bytes of scratch per lane
+            since_fold += nq;
+            if (since_fold >= FOLD_EVERY) {
+                since_fold = 0;
+                int Rl = R;
+                asm volatile("" : "+s"(Rl));
 #pragma unroll
-                    for (int ty = 0; ty < PXH; ++ty)
+                for (int ty = 0; ty < PXH; ++ty)
 #pragma unroll
-                        for (int tx = 0; tx < 4; ++tx) {
-                            const int p = ty * 4 + tx;
-                            const int gxp = px0 + ((lg - tx) & 3);       // column slot tx
-                            if (gxp < R && py0 + ty < R) {
-                                double *d = a.img + ((size_t)(py0 + ty) * R + gxp) * C;
+                    for (int tx = 0; tx < 4; ++tx) {
+                        const int p = ty * 4 + tx;
+                        const int gxp = px0 + ((lg - tx) & 3);       // column slot tx
+                        if (gxp < Rl && py0 + ty < Rl) {
+                            double *d = a.img + ((size_t)(py0 + ty) * Rl + gxp) * C;
 #pragma unroll
-                                for (int c = 0; c < NACC; ++c) {
-                                    if (acc[p][c] != 0.0f) gatomic_add(d + c, acc[p][c]);
-                                    acc[p][c] = 0.0f;
-                                }
+                            for (int c = 0; c < NACC; ++c) {
+                                if (acc[p][c] != 0.0f) gatomic_add(d + c, acc[p][c]);
+                                acc[p][c] = 0.0f;
                             }
                         }
-                }
+                    }
             }
         }
         __syncthreads();
@@ -264,6 +275,7 @@ __global__ __launch_bounds__(HT, (NACC == 3) ? TSP_H_OCC3 : 4) void splat_huge_k
 
 template <int MODE, int NACC, int PXH>
 static int launch_huge(tsp_context *ctx, TileArgs ta, size_t smem_h, long long n_huge) {
+    TSP_REQUIRE(ta.n_records < (1ll << 31), TSP_EINVAL, "%lld deferred footprints in one render block (the tile-gather kernels index them with 32 bits)", ta.n_records);
     const uint32_t attr_bit = 1u << (3 + MODE * 3 + (NACC - 1));
     if (!(ctx->kernel_attr_done & attr_bit)) {
         TSP_HIP(hipFuncSetAttribute((const void *)splat_huge_kernel<MODE, NACC, PXH>,
@@ -369,7 +381,6 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 #pragma unroll
         for (int c = 0; c < NACC; ++c) acc[p][c] = 0.0f;
     unsigned long long n_frag = 0;
-    int since_fold = 0;
     const char *PTb = reinterpret_cast<const char *>(PT);
     __syncthreads();                                       // the only workgroup barrier: from here on the waves run free
     if (sx >= R || sy >= R) return;                        // a strip wholly outside the image (R not a multiple of the tile)
@@ -379,11 +390,12 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     // The four waves read the same records at about the same time (L1 / L2 hits).  Records are dealt to the `split`
     // workgroups of a tile in runs of HDEAL: consecutive records are spatial neighbours (consecutive chunks), so
     // every workgroup sees an even sample of the tile's footprints.
-    const long long n_runs = (a.n_records + HDEAL - 1) / HDEAL;
-    auto fetch = [&](long long run0, float4 &g, float &gw1, float &gw2) {
-        const long long ri = ((run0 + lane / HDEAL) * a.split + sp) * HDEAL + (lane & (HDEAL - 1));
+    // 32-bit record indices (the launcher refuses lists of 2^31 records or more)
+    const unsigned n_rec = (unsigned)a.n_records, n_runs = (n_rec + HDEAL - 1) / HDEAL, usplit = (unsigned)a.split;
+    auto fetch = [&](unsigned run0, float4 &g, float &gw1, float &gw2) {
+        const unsigned ri = ((run0 + lane / HDEAL) * usplit + sp) * HDEAL + (lane & (HDEAL - 1));
         g = make_float4(0.f, 0.f, 0.f, 0.f); gw1 = gw2 = 0.0f;
-        if (ri < a.n_records) {
+        if (ri < n_rec) {
             g = a.geom[ri];
             gw1 = a.w[ri * NW];
             if (NW == 2) gw2 = a.w[ri * NW + 1];
@@ -391,7 +403,12 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     };
     float4 g_next; float gw1_next, gw2_next;
     fetch(0, g_next, gw1_next, gw2_next);
-    for (long long run0 = 0; run0 * a.split < n_runs; run0 += 64 / HDEAL) {
+    // The record loop is cut into segments of >= FOLD_EVERY footprints (<= FOLD_EVERY + 63); the accumulators go to the
+    // float64 target between segments: ONE flush site, outside the hot loops (see splat_mega64_kernel)
+    unsigned run0 = 0;
+    do {
+    int since_fold = 0;
+    for (; run0 * usplit < n_runs && since_fold < FOLD_EVERY; run0 += 64 / HDEAL) {
         const float4 g = g_next;
         const float gw1 = gw1_next, gw2 = gw2_next;
         fetch(run0 + 64 / HDEAL, g_next, gw1_next, gw2_next);      // the next 64 records load while these are rasterised
@@ -404,6 +421,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
         }
         unsigned long long hits = __ballot(hit);
         if (hits == 0ull) continue;
+        since_fold += __popcll(hits);
         const float g_invP = 1.0f / g.z;
         const float g_w1 = (MODE == TSP_MODE_RGB) ? gw1 : g.w * gw1;
         while (hits) {
@@ -536,45 +554,30 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 #undef TSP_H2_GROUP
 #undef TSP_H2_ROW
             if (a.count_frag) n_frag += (unsigned long long)(ncov_x * __popc(covmask));
-            if (++since_fold == FOLD_EVERY) {
-                since_fold = 0;
-                double *img = a.img + ((size_t)sy * R + (sx + lane)) * C;
-                asm volatile("" : "+v"(img));        // addresses are formed here, not hoisted to the kernel entry and spilled
-#pragma unroll
-                for (int ty = 0; ty < HR; ++ty)
-#pragma unroll
-                    for (int w = 0; w < W; ++w) {
-                        const int p = ty * W + w, gx = sx + 64 * w + lane, gy = sy + ty;
-                        if (gx < R && gy < R) {
-                            double *d = img + ((size_t)ty * R + 64 * w) * C;
-#pragma unroll
-                            for (int c = 0; c < NACC; ++c) {
-                                if (acc[p][c] != 0.0f) gatomic_add(d + c, acc[p][c]);
-                                acc[p][c] = 0.0f;
-                            }
-                        }
-                    }
-            }
         }
     }
     // ---- add this wave's partial strip into the render target ---------------------------------------
-    double *img_end = a.img + ((size_t)sy * R + (sx + lane)) * C;
-    asm volatile("" : "+v"(img_end));
+    {
+        int Rl = R;                                   // laundered: the row offsets are formed here, not hoisted out of the record loop
+        asm volatile("" : "+s"(Rl));
+        double *img = a.img + ((size_t)sy * Rl + (sx + lane)) * C;
+        asm volatile("" : "+v"(img));
 #pragma unroll
-    for (int ty = 0; ty < HR; ++ty) {
+        for (int ty = 0; ty < HR; ++ty)
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-            const int p = ty * W + w, gx = sx + 64 * w + lane, gy = sy + ty;
-            if (gx < R && gy < R) {
-                double *d = img_end + ((size_t)ty * R + 64 * w) * C;
+            for (int w = 0; w < W; ++w) {
+                const int p = ty * W + w, gx = sx + 64 * w + lane, gy = sy + ty;
+                if (gx < Rl && gy < Rl) {
+                    double *d = img + ((size_t)ty * Rl + 64 * w) * C;
 #pragma unroll
-                for (int c = 0; c < NACC; ++c) {
-                    const float v = acc[p][c];
-                    if (v != 0.0f) gatomic_add(d + c, v);
+                    for (int c = 0; c < NACC; ++c) {
+                        if (acc[p][c] != 0.0f) gatomic_add(d + c, acc[p][c]);
+                        acc[p][c] = 0.0f;
+                    }
                 }
             }
-        }
     }
+    } while (run0 * usplit < n_runs);
     if (a.count_frag) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
         if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[2], n_frag); }
@@ -583,6 +586,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 
 template <int MODE, int NACC, int W, int HR, int OCC>
 static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
+    TSP_REQUIRE(ta.n_records < (1ll << 31), TSP_EINVAL, "%lld deferred footprints in one render block (the tile-gather kernels index them with 32 bits)", ta.n_records);
     const size_t smem = (size_t)((PT_ROWS * PT_STRIDE + 3) & ~3) * sizeof(float) + (H2T / 64) * HR * sizeof(float2);
     const int tw = 2 * 64 * W, th = 2 * HR;
     const int htiles_x = (ctx->R + tw - 1) / tw, htiles_y = (ctx->R + th - 1) / th;
@@ -652,21 +656,22 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[c][b][v] = 0.0f;
     unsigned long long n_frag = 0;
-    int since_fold = 0;
     const char *PTb = reinterpret_cast<const char *>(PT);
     __syncthreads();                                       // the only workgroup barrier
     if (sx >= R || sy >= R) return;                        // a strip wholly outside the image (last_row would be negative)
 
     auto flush = [&]() {
-        double *img = a.img + ((size_t)(sy + 4 * kh) * R + (sx + li)) * C;
+        int Rl = R;                                        // laundered: see splat_mega64_kernel
+        asm volatile("" : "+s"(Rl));
+        double *img = a.img + ((size_t)(sy + 4 * kh) * Rl + (sx + li)) * C;
         asm volatile("" : "+v"(img));
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int row = (v >> 2) * 8 + (v & 3);    // + 4 * kh (in img)
-                if (sx + 32 * b + li < R && sy + 4 * kh + row < R) {
-                    double *d = img + ((size_t)row * R + 32 * b) * C;
+                if (sx + 32 * b + li < Rl && sy + 4 * kh + row < Rl) {
+                    double *d = img + ((size_t)row * Rl + 32 * b) * C;
 #pragma unroll
                     for (int c = 0; c < NACC; ++c) {
                         if (acc[c][b][v] != 0.0f) gatomic_add(d + c, acc[c][b][v]);
@@ -676,11 +681,11 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
             }
     };
 
-    const long long n_runs = (a.n_records + HDEAL - 1) / HDEAL;
-    auto fetch = [&](long long run0, float4 &g, float &gw1, float &gw2) {
-        const long long ri = ((run0 + lane / HDEAL) * a.split + sp) * HDEAL + (lane & (HDEAL - 1));
+    const unsigned n_rec = (unsigned)a.n_records, n_runs = (n_rec + HDEAL - 1) / HDEAL, usplit = (unsigned)a.split;
+    auto fetch = [&](unsigned run0, float4 &g, float &gw1, float &gw2) {
+        const unsigned ri = ((run0 + lane / HDEAL) * usplit + sp) * HDEAL + (lane & (HDEAL - 1));
         g = make_float4(0.f, 0.f, 0.f, 0.f); gw1 = gw2 = 0.0f;
-        if (ri < a.n_records) {
+        if (ri < n_rec) {
             g = a.geom[ri];
             gw1 = a.w[ri * NW];
             if (NW == 2) gw2 = a.w[ri * NW + 1];
@@ -688,7 +693,10 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
     };
     float4 g_next; float gw1_next, gw2_next;
     fetch(0, g_next, gw1_next, gw2_next);
-    for (long long run0 = 0; run0 * a.split < n_runs; run0 += 64 / HDEAL) {
+    unsigned run0 = 0;
+    do {                                                   // segments of >= FOLD_EVERY footprints, one flush site (see splat_mega64_kernel)
+    int since_fold = 0;
+    for (; run0 * usplit < n_runs && since_fold < FOLD_EVERY; run0 += 64 / HDEAL) {
         const float4 g = g_next;
         const float gw1 = gw1_next, gw2 = gw2_next;
         fetch(run0 + 64 / HDEAL, g_next, gw1_next, gw2_next);
@@ -700,6 +708,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
         }
         unsigned long long hits = __ballot(hit);
         if (hits == 0ull) continue;
+        since_fold += __popcll(hits);
         const float g_invP = 1.0f / g.z;
         const float g_w1 = (MODE == TSP_MODE_RGB) ? gw1 : g.w * gw1;
         while (hits) {
@@ -797,10 +806,10 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
                         if (NACC >= 3) acc[NACC - 1][b][v] = __builtin_fmaf(kimg[b][v], w2, acc[NACC - 1][b][v]);
                     }
             }
-            if (++since_fold == FOLD_EVERY) { since_fold = 0; flush(); }
         }
     }
     flush();
+    } while (run0 * usplit < n_runs);
     if (a.count_frag) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
         if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[3], n_frag); }
@@ -845,23 +854,26 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega64_kernel(TileArgs a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[rb][b][v] = 0.0f;
     unsigned long long n_frag = 0;
-    int since_fold = 0;
     const char *PTb = reinterpret_cast<const char *>(PT);
     __syncthreads();
     if (sx >= R || sy >= R) return;
 
     auto flush = [&]() {
+        // R is laundered here so that the 64 row / block offsets below are formed at the flush, not hoisted out of the record
+        // loop as loop invariants (they filled the scalar file and spilled into VGPR lanes)
+        int Rl = R;
+        asm volatile("" : "+s"(Rl));
 #pragma unroll
         for (int rb = 0; rb < NR; ++rb) {
-            double *img = a.img + ((size_t)(sy + 32 * rb + 4 * kh) * R + (sx + li)) * C;
+            double *img = a.img + ((size_t)(sy + 32 * rb + 4 * kh) * Rl + (sx + li)) * C;
             asm volatile("" : "+v"(img));
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int row = (v >> 2) * 8 + (v & 3);
-                    if (sx + 32 * b + li < R && sy + 32 * rb + 4 * kh + row < R) {
-                        double *d = img + ((size_t)row * R + 32 * b) * C;
+                    if (sx + 32 * b + li < Rl && sy + 32 * rb + 4 * kh + row < Rl) {
+                        double *d = img + ((size_t)row * Rl + 32 * b) * C;
                         if (acc[rb][b][v] != 0.0f) gatomic_add(d, acc[rb][b][v]);
                         acc[rb][b][v] = 0.0f;
                     }
@@ -869,15 +881,23 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega64_kernel(TileArgs a) {
         }
     };
 
-    const long long n_runs = (a.n_records + HDEAL - 1) / HDEAL;
-    auto fetch = [&](long long run0, float4 &g) {
-        const long long ri = ((run0 + lane / HDEAL) * a.split + sp) * HDEAL + (lane & (HDEAL - 1));
+    // 32-bit record indices (the launcher refuses lists of 2^31 records or more)
+    const unsigned n_rec = (unsigned)a.n_records, n_runs = (n_rec + HDEAL - 1) / HDEAL, usplit = (unsigned)a.split;
+    auto fetch = [&](unsigned run0, float4 &g) {
+        const unsigned ri = ((run0 + lane / HDEAL) * usplit + sp) * HDEAL + (lane & (HDEAL - 1));
         g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ri < a.n_records) g = a.geom[ri];
+        if (ri < n_rec) g = a.geom[ri];
     };
     float4 g_next;
     fetch(0, g_next);
-    for (long long run0 = 0; run0 * a.split < n_runs; run0 += 64 / HDEAL) {
+    // The record loop is cut into segments of >= FOLD_EVERY footprints (<= FOLD_EVERY + 63), the accumulators go to the
+    // float64 target BETWEEN segments: one flush site outside the hot loops.  (With the flush inlined under the innermost
+    // loop the register allocator parked three of the four accumulator blocks in scratch around every 64-record batch:
+    // 6.6 GB of spill writes per launch, profiles/round3g.)
+    unsigned run0 = 0;
+    do {
+    int since_fold = 0;
+    for (; run0 * usplit < n_runs && since_fold < FOLD_EVERY; run0 += 64 / HDEAL) {
         const float4 g = g_next;
         fetch(run0 + 64 / HDEAL, g_next);
         const float g_half = 0.5f * g.z;
@@ -888,6 +908,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega64_kernel(TileArgs a) {
         }
         unsigned long long hits = __ballot(hit);
         if (hits == 0ull) continue;
+        since_fold += __popcll(hits);
         const float g_invP = 1.0f / g.z;
         while (hits) {
             const int src = __ffsll((long long)hits) - 1;
@@ -945,10 +966,10 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega64_kernel(TileArgs a) {
                     rowoff += 2 * PT_STRIDE * 4;
                 }
             }
-            if (++since_fold == FOLD_EVERY) { since_fold = 0; flush(); }
         }
     }
     flush();
+    } while (run0 * usplit < n_runs);
     if (a.count_frag) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
         if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[3], n_frag); }
@@ -957,6 +978,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega64_kernel(TileArgs a) {
 
 template <int MODE, int OCC>
 static int launch_mega64(tsp_context *ctx, TileArgs ta, long long n_huge) {
+    TSP_REQUIRE(ta.n_records < (1ll << 31), TSP_EINVAL, "%lld deferred footprints in one render block (the tile-gather kernels index them with 32 bits)", ta.n_records);
     const size_t smem = (size_t)((PT_ROWS * PT_STRIDE + 3) & ~3) * sizeof(float);
     const int htiles_x = (ctx->R + 127) / 128, htiles_y = (ctx->R + 127) / 128;
     const int htiles = htiles_x * htiles_y;
@@ -973,6 +995,7 @@ static int launch_mega64(tsp_context *ctx, TileArgs ta, long long n_huge) {
 
 template <int MODE, int NACC, int NB, int OCC>
 static int launch_mega(tsp_context *ctx, TileArgs ta, long long n_huge) {
+    TSP_REQUIRE(ta.n_records < (1ll << 31), TSP_EINVAL, "%lld deferred footprints in one render block (the tile-gather kernels index them with 32 bits)", ta.n_records);
     const size_t smem = (size_t)((PT_ROWS * PT_STRIDE + 3) & ~3) * sizeof(float);
     const int htiles_x = (ctx->R + 64 * NB - 1) / (64 * NB), htiles_y = (ctx->R + 63) / 64;
     const int htiles = htiles_x * htiles_y;
