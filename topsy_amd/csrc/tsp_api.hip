@@ -717,17 +717,17 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         return TSP_OK;
     }
     if (!strcmp(name, "mega_variant")) {
-        TSP_REQUIRE(value >= 0 && value <= 3, TSP_EINVAL, "mega_variant out of range");
+        TSP_REQUIRE(value >= 0 && value <= 5, TSP_EINVAL, "mega_variant out of range");
         ctx->mega_variant = (int)value;
         return TSP_OK;
     }
     if (!strcmp(name, "rgb_mega_variant")) {
-        TSP_REQUIRE(value >= 0 && value <= 3, TSP_EINVAL, "rgb_mega_variant out of range");
+        TSP_REQUIRE(value >= 0 && value <= 4, TSP_EINVAL, "rgb_mega_variant out of range");
         ctx->rgb_mega_variant = (int)value;
         return TSP_OK;
     }
     if (!strcmp(name, "huge_variant")) {
-        TSP_REQUIRE(value >= 0 && value <= 3, TSP_EINVAL, "huge_variant out of range");
+        TSP_REQUIRE(value >= 0 && value <= 7, TSP_EINVAL, "huge_variant out of range");
         ctx->huge_variant = (int)value;
         return TSP_OK;
     }

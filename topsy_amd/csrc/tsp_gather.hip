@@ -474,9 +474,16 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
                 chgmask |= first; jmpmask |= first;
             }
             // row factors of group k for the DPP broadcast: lane l takes rows 4k + (l & 3)
-            float2 rowf[NG];
+            // HR = 16: the four groups' factors sit in registers; HR = 32: two registers pairs in turn (group K + 1 loads while
+            // group K is walked), 12 VGPRs fewer -- what lets the 64 x 32 strips run at 6 waves per SIMD
+            constexpr bool JIT = (HR == 32);
+            constexpr int NRF = JIT ? 2 : NG;
+            float2 rowf[NRF];
+            if constexpr (JIT) rowf[0] = rt_quad[0];
+            else {
 #pragma unroll
-            for (int k = 0; k < NG; ++k) rowf[k] = rt_quad[4 * k];
+                for (int k = 0; k < NG; ++k) rowf[k] = rt_quad[4 * k];
+            }
             // ---- columns: W per lane ----
             int caddr[W];
             float fxs[W], gxs[W];
@@ -522,9 +529,11 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             // slots).  The DPP operands below are the row factors: they come from LDS (no VALU write) long before their use,
             // and the compiler does not see inside the asm statements, so pin them in registers here and leave two wait
             // states; the other operands of the DPP FMAs (top, bot) are ordinary sources and carry no such restriction.
+            if constexpr (!JIT) {
 #pragma unroll
-            for (int k = 0; k < NG; ++k) asm volatile("" : "+v"(rowf[k].x), "+v"(rowf[k].y));
-            asm volatile("s_nop 1");
+                for (int k = 0; k < NG; ++k) asm volatile("" : "+v"(rowf[k].x), "+v"(rowf[k].y));
+                asm volatile("s_nop 1");
+            }
 #define TSP_H2_ROW(K, T)                                                                                       \
             {                                                                                                  \
                 constexpr int ty_ = 4 * (K) + (T);                                                             \
@@ -532,11 +541,11 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
                 _Pragma("unroll") for (int w = 0; w < W; ++w) {                                                \
                     float *ac = acc[ty_ * W + w];                                                              \
                     if (NACC == 1) {                                                                           \
-                        fmac_quad<T>(ac[0], rowf[K].y, top[w]);                                                \
-                        fmac_quad<T>(ac[0], rowf[K].x, bot[w]);                                                \
+                        fmac_quad<T>(ac[0], rowf[JIT ? ((K) & 1) : (K)].y, top[w]);                                                \
+                        fmac_quad<T>(ac[0], rowf[JIT ? ((K) & 1) : (K)].x, bot[w]);                                                \
                     } else {                                                                                   \
-                        float kv = mul_quad<T>(rowf[K].y, top[w]);                                             \
-                        fmac_quad<T>(kv, rowf[K].x, bot[w]);                                                   \
+                        float kv = mul_quad<T>(rowf[JIT ? ((K) & 1) : (K)].y, top[w]);                                             \
+                        fmac_quad<T>(kv, rowf[JIT ? ((K) & 1) : (K)].x, bot[w]);                                                   \
                         fmac_plain(ac[0], kv, wq.x);                                                           \
                         fmac_plain(ac[NACC >= 2 ? 1 : 0], kv, wq.y);                                           \
                         if (NACC >= 3) fmac_plain(ac[NACC - 1], kv, wq.z);                                     \
@@ -548,12 +557,25 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             // skipped.  (Laying the change out of line as the unlikely path measured slower: this kernel serves the
             // footprints below p_mega, whose texel rows change every 1-8 pixel rows.)
 #define TSP_H2_GROUP(K)                                                                                        \
-            if constexpr ((K) < NG) { if (((covmask >> (4 * (K))) & 15u) != 0u) { TSP_H2_ROW(K, 0) TSP_H2_ROW(K, 1) TSP_H2_ROW(K, 2) TSP_H2_ROW(K, 3) } }
+            if constexpr ((K) < NG) {                                                                          \
+                if constexpr (JIT && (K) + 1 < NG) rowf[((K) + 1) & 1] = rt_quad[4 * ((K) + 1)];               \
+                if (((covmask >> (4 * (K))) & 15u) != 0u) {                                                    \
+                    if constexpr (JIT) asm volatile("" : "+v"(rowf[(K) & 1].x), "+v"(rowf[(K) & 1].y));        \
+                    TSP_H2_ROW(K, 0) TSP_H2_ROW(K, 1) TSP_H2_ROW(K, 2) TSP_H2_ROW(K, 3)                          \
+                }                                                                                              \
+            }
             TSP_H2_GROUP(0) TSP_H2_GROUP(1) TSP_H2_GROUP(2) TSP_H2_GROUP(3)
             TSP_H2_GROUP(4) TSP_H2_GROUP(5) TSP_H2_GROUP(6) TSP_H2_GROUP(7)
 #undef TSP_H2_GROUP
 #undef TSP_H2_ROW
             if (a.count_frag) n_frag += (unsigned long long)(ncov_x * __popc(covmask));
+#ifdef TSP_H2_DEBUG      // analysis build: (footprint, strip) pairs, covered rows and texel-row changes instead of the S / M / H3 fragment counts
+            if (a.count_frag && lane == 0) {
+                atomicAdd(&a.cnt->n_frag_class[0], 1ull);
+                atomicAdd(&a.cnt->n_frag_class[1], (unsigned long long)__popc(covmask));
+                atomicAdd(&a.cnt->n_frag_class[3], (unsigned long long)__popc(chgmask));
+            }
+#endif
         }
     }
     // ---- add this wave's partial strip into the render target ---------------------------------------
@@ -1239,7 +1261,11 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
         // rgb stays on kernel H: with three accumulators per pixel its per-pixel stencil set-up is shared by three FMAs
         // (0.49 clk per fragment at 2048^2), while H2 pays its per-strip set-up over 16-row strips (0.62) and H3 needs
         // three MFMAs per block and k-step (0.47)
-        if (ctx->huge_variant == 0 || MODE == TSP_MODE_RGB) {
+        // rgb: kernel H2 with three accumulator sets since round 4 (116 VGPRs once its flush left the hot loop: 13.0 ms against
+        // kernel H's 14.8 ms for the 64-128 px band of config 4); huge_variant 0 keeps kernel H for A/B
+        if (MODE == TSP_MODE_RGB && ctx->huge_variant != 0) {
+            rc = launch_huge2<MODE, 3, 1, 16, 4>(ctx, ta, n_huge);
+        } else if (ctx->huge_variant == 0 || MODE == TSP_MODE_RGB) {
             const size_t smem_h = (size_t)(64 * 64 + 512) * sizeof(float4);
             if (MODE == TSP_MODE_RGB) rc = launch_huge<MODE, 3, 4>(ctx, ta, smem_h, n_huge);
             else if (second_channel) rc = launch_huge<MODE, 2, 4>(ctx, ta, smem_h, n_huge);
@@ -1248,9 +1274,20 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
             if (second_channel) rc = launch_tile4<MODE, 2, 5>(ctx, ta, n_huge);
             else rc = launch_tile4<MODE, 1, 6>(ctx, ta, n_huge);
         } else {                                // kernel H2 (row-uniform gather): 64 px <= P < p_mega
-            if (second_channel) rc = launch_huge2<MODE, 2, 1, 16, 4>(ctx, ta, n_huge);      // 5-6 waves/SIMD spill: 21 / 31 vs 16 ms
-            else if (ctx->huge_variant == 2) rc = launch_huge2<MODE, 1, 1, 32, 4>(ctx, ta, n_huge);     // (round 3: 12.0 vs 10.5 ms; at 5 waves/SIMD 12.7)
-            else rc = launch_huge2<MODE, 1, 1, 16, 6>(ctx, ta, n_huge);   // 64x16 strips at 6 waves/SIMD: 17.3 ms against 18.6 for 64x32 at 4
+            if (second_channel) {
+                if (ctx->huge_variant == 4) rc = launch_huge2<MODE, 2, 1, 16, 5>(ctx, ta, n_huge);
+                else rc = launch_huge2<MODE, 2, 1, 16, 4>(ctx, ta, n_huge);      // 5-6 waves/SIMD spill: 21 / 31 vs 16 ms
+            }
+            else if (ctx->huge_variant == 2) rc = launch_huge2<MODE, 1, 1, 32, 4>(ctx, ta, n_huge);
+            else if (ctx->huge_variant == 4) rc = launch_huge2<MODE, 1, 1, 16, 7>(ctx, ta, n_huge);
+            else if (ctx->huge_variant == 5) rc = launch_huge2<MODE, 1, 1, 16, 8>(ctx, ta, n_huge);
+            else if (ctx->huge_variant == 6) rc = launch_huge2<MODE, 1, 1, 16, 6>(ctx, ta, n_huge);
+            // Round 4, once the flush had left the hot loop (no scratch, 64-80 VGPRs): 64x32 strips at 6 waves/SIMD with the row
+            // factors fetched group by group -- half as many (footprint, strip) pairs to set up: 8.64 ms (1.25e8 particles) /
+            // 24.4 ms (1e9) against 9.0 / 27.4 for 64x16 strips at 8 waves/SIMD, 9.3 at 6, 9.5 at 7; 64x32 at 4: 9.4
+            // (with fewer records the shorter strips' finer work units win: 3.4e5 records 2.57 against 2.79 ms, 1.4e5: 1.27 against 1.73)
+            else if (ctx->huge_variant == 7 || (ctx->huge_variant == 1 && n_huge >= 700000)) rc = launch_huge2<MODE, 1, 1, 32, 6>(ctx, ta, n_huge);
+            else rc = launch_huge2<MODE, 1, 1, 16, 8>(ctx, ta, n_huge);
         }
         if (rc) return rc;
     }
@@ -1272,12 +1309,20 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
             // three accumulator sets (96 registers for a 64 x 32 strip): 2-3 waves per SIMD of the 512-entry register file
             if (ctx->rgb_mega_variant == 1) rc = launch_mega<MODE, 3, 2, 2>(ctx, ta, n_mega);
             else if (ctx->rgb_mega_variant == 2) rc = launch_mega<MODE, 3, 2, 3>(ctx, ta, n_mega);
+            else if (ctx->rgb_mega_variant == 4) rc = launch_mega<MODE, 3, 1, 4>(ctx, ta, n_mega);
             else rc = launch_mega<MODE, 3, 1, 3>(ctx, ta, n_mega);
-        } else if (second_channel) rc = launch_mega<MODE, 2, 2, 3>(ctx, ta, n_mega);      // 64 accumulator + 32 scratch registers: 3 waves/SIMD (4 would spill)
+        } else if (second_channel) {
+            // 64x32 strips at 4 waves/SIMD (spills 112 B outside the k-loop) 13.16 ms against 13.37 at 3 (1.25e8 weighted); with
+            // few records the narrower 32x32 strips (more, shorter workgroups) win: 1e7 weighted 4.08 against 4.49 / 4.66 ms
+            if (ctx->mega_variant == 3) rc = launch_mega<MODE, 2, 2, 3>(ctx, ta, n_mega);
+            else if (ctx->mega_variant == 5 || (ctx->mega_variant == 0 && n_mega < 100000)) rc = launch_mega<MODE, 2, 1, 4>(ctx, ta, n_mega);
+            else rc = launch_mega<MODE, 2, 2, 4>(ctx, ta, n_mega);
+        }
         // density: 64 x 64 strips (column factors and parameters prepared once per 4096 pixels) once there are enough records to
         // keep their fewer, longer workgroups busy: 1.25e8 particles 6.3 -> 6.0 ms, 1e9: 18.2 -> 17.3 ms, but 1e7: 2.1 -> 2.25 ms
         else if (ctx->mega_variant == 2 || (ctx->mega_variant == 0 && n_mega >= 40000)) rc = launch_mega64<MODE, 4>(ctx, ta, n_mega);
         else if (ctx->mega_variant == 3) rc = launch_mega64<MODE, 3>(ctx, ta, n_mega);
+        else if (ctx->mega_variant == 4) rc = launch_mega<MODE, 1, 2, 5>(ctx, ta, n_mega);
         else rc = launch_mega<MODE, 1, 2, 4>(ctx, ta, n_mega);   // 4 column blocks per strip and 5-6 waves/SIMD measured no faster
         if (rc) return rc;
     }

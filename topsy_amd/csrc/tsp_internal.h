@@ -124,7 +124,7 @@ struct tsp_context {
     unsigned long long int_edge[2] = {0, 0};   // kernel I: rows of S0 with a non-zero edge jump (bit q of 66)
     double *int_tables = nullptr;     // kernel I: breakpoint strengths of the level-0 kernel image and their prefix sums (integrated_tables)
     int mega_variant = 0;             // density: 0 = auto, 1 = kernel H3 on 64 x 32 strips, 2 / 3 = on 64 x 64 strips at 4 / 3 waves per SIMD
-    int rgb_mega_variant = 3;         // rgb: 0 = every footprint >= 64 px on kernel H; 1-3: those >= p_mega on kernel H3 with three accumulator sets
+    int rgb_mega_variant = 2;         // rgb: 0 = every footprint >= 64 px on kernel H / H2; 1-4: those >= p_mega on kernel H3 with three accumulator sets (2: 64x32 strips at 3 waves/SIMD, 50.9 ms against 53.5 for 32x32 strips at config 4)
     int huge_variant = 1;             // 0: kernel H (per-pixel gather, A/B only), 1: kernels H2 (64x16 strips) + H3, 2: H2 with 64x32 strips (density)
     int mid_split = 128, huge_split = 0, mega_split = 0;  // workgroups per image tile (0 = auto)
     int stream_blocks_per_cu = 100;  // kernel S grid bound: ~10 chunks per workgroup at 1e8 particles balances dense and sparse chunks
