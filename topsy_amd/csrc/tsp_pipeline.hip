@@ -29,6 +29,10 @@
 
 #include "tsp_pipeline.h"
 
+#ifndef TSP_S_PAIRMERGE
+#define TSP_S_PAIRMERGE 0      // experiment: kernel S sums lane pairs that hit one pixel before the LDS atomic (measured: see DESIGN.md)
+#endif
+
 namespace tsp {
 
 // ---------------------------------------------------------------------------------------------
@@ -107,7 +111,16 @@ struct StreamArgs {
 // WC = channels kept in the LDS window: 1 for a density-only render (channel 1 is identically 0:
 // half the LDS and half the atomics), else the image's channel count.
 template <int MODE, int WC>
-__global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamArgs a) {
+__global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamArgs /*read through the kernarg pointer*/) {
+    // The ~45 arguments are NOT held in scalar registers for the whole kernel (they overflowed the scalar file: > 100 SGPRs
+    // spilled into VGPR lanes and came back through ~380 v_readlane -- a fifth of the VALU instructions of the raster phase):
+    // every phase reads the few it needs from the kernarg segment again (s_load through a laundered pointer).
+    typedef const __attribute__((address_space(4))) StreamArgs CArgs;
+    auto KA = []() -> CArgs * {
+        CArgs *p = (CArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(p));
+        return p;
+    };
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;      // extra weights per record
     constexpr int WIN = WinSize<WC>::value;
@@ -119,10 +132,16 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
     __shared__ long long s_base[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const Camera &cam = a.cam;
-    const int R = cam.R;
-    for (int i = tid; i < WC * WIN * WIN; i += SBLOCK) win[i] = 0.0;
-    for (int i = tid; i < 320; i += SBLOCK) T23[i] = a.mips[5120 + i];
+    int R, c_begin, c_end;
+    {
+        CArgs *ap = KA();
+        R = ap->cam.R;
+        const float *mips = ap->mips;
+        for (int i = tid; i < WC * WIN * WIN; i += SBLOCK) win[i] = 0.0;
+        for (int i = tid; i < 320; i += SBLOCK) T23[i] = mips[5120 + i];
+        c_begin = blockIdx.x * ap->chunks_per_block;
+        c_end = min(c_begin + ap->chunks_per_block, ap->n_chunks);
+    }
     __syncthreads();
 
     // window state (uniform): origin and the dirty rectangle (window coordinates, inclusive)
@@ -130,13 +149,11 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
     int dx0 = WIN, dy0 = WIN, dx1 = -1, dy1 = -1;
     unsigned long long n_small = 0, n_cull = 0, n_frag = 0;
 
-    const int c_begin = blockIdx.x * a.chunks_per_block;
-    const int c_end = min(c_begin + a.chunks_per_block, a.n_chunks);
-    const int64_t *starts = a.ranges, *lens = a.ranges + a.n_ranges, *cprefix = a.ranges + 2 * a.n_ranges;
 
     auto flush = [&]() {
         // one global atomic per touched pixel and channel; only the dirty rectangle is visited
         if (dx1 >= dx0) {
+            double *img = KA()->img;
             const int fw = dx1 - dx0 + 1, fn = fw * (dy1 - dy0 + 1);
             for (int idx = tid; idx < fn; idx += SBLOCK) {
                 const int jj = idx / fw;
@@ -147,7 +164,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                 for (int c = 0; c < WC; ++c) {
                     const double v = win[c * WIN * WIN + o];
                     if (v != 0.0) {
-                        if (gx < R && gy < R) gatomic_add(a.img + ((size_t)gy * R + gx) * C + c, v);
+                        if (gx < R && gy < R) gatomic_add(img + ((size_t)gy * R + gx) * C + c, v);
                         win[c * WIN * WIN + o] = 0.0;
                     }
                 }
@@ -158,9 +175,12 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
 
     // locate chunk c: range r, particles [first, first + cnt)
     auto locate = [&](int c, int64_t &first, int &cnt) {
+        CArgs *ap = KA();
+        const int n_ranges = ap->n_ranges;
+        const int64_t *starts = ap->ranges, *lens = starts + n_ranges, *cprefix = starts + 2 * n_ranges;
         int r = 0;
-        if (a.n_ranges > 1) {
-            int lo = 0, hi = a.n_ranges - 1;
+        if (n_ranges > 1) {
+            int lo = 0, hi = n_ranges - 1;
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
                 if (cprefix[mid] <= c) lo = mid; else hi = mid - 1;
@@ -176,17 +196,20 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
     constexpr int NATTR = (MODE == TSP_MODE_RGB) ? 7 : 6;      // x y z h + (m, q) or (r, g, b)
     float L[KPT][NATTR];
     auto load_chunk = [&](int64_t first, int cnt) {
+        CArgs *ap = KA();
+        const float *qx = ap->p.x, *qy = ap->p.y, *qz = ap->p.z, *qh = ap->p.h;
+        const float *q4 = (MODE == TSP_MODE_RGB) ? ap->p.r : ap->p.m;
+        const float *q5 = (MODE == TSP_MODE_RGB) ? ap->p.g : ((MODE != TSP_MODE_DEPTH) ? ap->p.q : nullptr);
+        const float *q6 = (MODE == TSP_MODE_RGB) ? ap->p.b : nullptr;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            const int li = k * SBLOCK + tid;
-#pragma unroll
-            for (int t = 0; t < NATTR; ++t) L[k][t] = 0.0f;
-            if (li < cnt) {
-                const int64_t i = first + li;
-                L[k][0] = a.p.x[i]; L[k][1] = a.p.y[i]; L[k][2] = a.p.z[i]; L[k][3] = a.p.h[i];
-                if (MODE == TSP_MODE_RGB) { L[k][4] = a.p.r[i]; L[k][5] = a.p.g[i]; L[k][6] = a.p.b[i]; }
-                else { L[k][4] = a.p.m[i]; L[k][5] = (MODE != TSP_MODE_DEPTH && a.p.q) ? a.p.q[i] : 0.0f; }
-            }
+            // lanes past the end of a short chunk load its last particle again (cnt >= 1): no predication, no zero fill;
+            // the classification masks them out
+            const int64_t i = first + min(k * SBLOCK + tid, cnt - 1);
+            L[k][0] = qx[i]; L[k][1] = qy[i]; L[k][2] = qz[i]; L[k][3] = qh[i];
+            L[k][4] = q4[i];
+            if (MODE == TSP_MODE_RGB) { L[k][5] = q5[i]; L[k][NATTR - 1] = q6[i]; }
+            else L[k][5] = q5 ? q5[i] : 0.0f;
         }
     };
     int64_t first = 0, first_next = 0;
@@ -203,51 +226,52 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         unsigned s_lo = 0xffffffffu, s_hi = 0u;      // covered-pixel bounding box of the small footprints: (ilo | jlo << 16), (ihi | jhi << 16)
         unsigned m_lo = 0xffffffffu, m_hi = 0u;      // the same for the mid footprints
         int my_counts = 0;                           // mid records | huge records << 16 of this lane
+        Camera cam;                                  // (16 scalar registers, live in this phase only)
+        float p_small, p_mega;
+        {
+            CArgs *ap = KA();
+#pragma unroll
+            for (int i = 0; i < 12; ++i) cam.m[i] = ap->cam.m[i];
+            cam.sf = ap->cam.sf; cam.Rf = ap->cam.Rf; cam.halfR = ap->cam.halfR; cam.R = R;
+            p_small = ap->p_small; p_mega = ap->p_mega;
+        }
+        // Branch-free: every lane runs the whole classification on whatever its registers hold (lanes past the end of the chunk
+        // re-read the chunk's last particle) and the outcome is masked at the end -- nothing below reads pcx .. w2, xr, yr of a
+        // particle whose class is CLS_NONE.  (As nested ifs with zeroed defaults the compiler re-materialised the fourteen
+        // defaults at every nesting level: a fifth of this phase's instructions were v_mov.)
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             const int li = k * SBLOCK + tid;
-            cls[k] = CLS_NONE;
-            pcx[k] = pcy[k] = PP[k] = invP[k] = w0[k] = w1[k] = w2[k] = 0.0f;
-            xr[k] = yr[k] = 0u;
-            if (li < cnt) {
-                const float h = L[k][3];
-                const Proj pr = project(cam, L[k][0], L[k][1], L[k][2], h);
-                bool vis = false;
-                int ilo = 0, ihi = 0, jlo = 0, jhi = 0;
-                if (pr.keep) {
-                    // any pixel centre covered?  (exact test via the canonical interval)
-                    cover_range(pr.pcx, pr.half, R, ilo, ihi);
-                    cover_range(pr.pcy, pr.half, R, jlo, jhi);
-                    vis = (ilo <= ihi) && (jlo <= jhi);
-                }
-                if (vis) {
-                    // a small footprint covers <= 16 pixels per axis and R <= 16384: both fit 16 bits
-                    xr[k] = (unsigned)ilo | ((unsigned)min(ihi - ilo + 1, 0xffff) << 16);
-                    yr[k] = (unsigned)jlo | ((unsigned)min(jhi - jlo + 1, 0xffff) << 16);
-                    const unsigned lo = (unsigned)ilo | ((unsigned)jlo << 16), hi = (unsigned)ihi | ((unsigned)jhi << 16);
-                    const float hh = h * h;
-                    if (MODE == TSP_MODE_RGB) {
-                        w0[k] = L[k][4] / hh; w1[k] = L[k][5] / hh; w2[k] = L[k][6] / hh;
-                    } else {
-                        w0[k] = L[k][4] / hh;
-                        w1[k] = (MODE == TSP_MODE_DEPTH) ? pr.cz : L[k][5];
-                    }
-                    pcx[k] = pr.pcx; pcy[k] = pr.pcy; PP[k] = pr.P; invP[k] = pr.invP;
-                    if (pr.P < a.p_small) {
-                        cls[k] = CLS_SMALL;
-                        s_lo = pk_min_u16(s_lo, lo); s_hi = pk_max_u16(s_hi, hi);
-                    } else if (pr.P < P_BILINEAR) {
-                        cls[k] = CLS_MID; my_counts += 1;
-                        m_lo = pk_min_u16(m_lo, lo); m_hi = pk_max_u16(m_hi, hi);
-                    } else if (pr.P < a.p_mega) {
-                        cls[k] = CLS_HUGE; my_counts += 1 << 16;
-                    } else {
-                        cls[k] = CLS_MEGA;          // rare (~1e-3 of the particles): one atomic each, below
-                    }
-                } else {
-                    ++n_cull;
-                }
+            const bool in_chunk = li < cnt;
+            const float h = L[k][3];
+            const Proj pr = project(cam, L[k][0], L[k][1], L[k][2], h);
+            int ilo = 1, ihi = 0, jlo = 1, jhi = 0;
+            if (__ballot(in_chunk && pr.keep) != 0ull) {        // (a chunk wholly outside the z-slab skips the range arithmetic)
+                // any pixel centre covered?  (exact test via the canonical interval)
+                cover_range(pr.pcx, pr.half, R, ilo, ihi);
+                cover_range(pr.pcy, pr.half, R, jlo, jhi);
             }
+            const bool vis = in_chunk && pr.keep && (ilo <= ihi) && (jlo <= jhi);
+            // a small footprint covers <= 16 pixels per axis and R <= 16384: both fit 16 bits
+            xr[k] = (unsigned)ilo | ((unsigned)min(ihi - ilo + 1, 0xffff) << 16);
+            yr[k] = (unsigned)jlo | ((unsigned)min(jhi - jlo + 1, 0xffff) << 16);
+            const unsigned lo = (unsigned)ilo | ((unsigned)jlo << 16), hi = (unsigned)ihi | ((unsigned)jhi << 16);
+            const float hh = h * h;
+            if (MODE == TSP_MODE_RGB) {
+                w0[k] = L[k][4] / hh; w1[k] = L[k][5] / hh; w2[k] = L[k][NATTR - 1] / hh;
+            } else {
+                w0[k] = L[k][4] / hh;
+                w1[k] = (MODE == TSP_MODE_DEPTH) ? pr.cz : L[k][5];
+                w2[k] = 0.0f;
+            }
+            pcx[k] = pr.pcx; pcy[k] = pr.pcy; PP[k] = pr.P; invP[k] = pr.invP;
+            const int c_of_p = (pr.P < p_small) ? CLS_SMALL : ((pr.P < P_BILINEAR) ? CLS_MID : ((pr.P < p_mega) ? CLS_HUGE : CLS_MEGA));
+            cls[k] = vis ? c_of_p : CLS_NONE;          // CLS_MEGA is rare (~1e-3 of the particles): one atomic each, below
+            const bool is_small = cls[k] == CLS_SMALL, is_mid = cls[k] == CLS_MID;
+            s_lo = is_small ? pk_min_u16(s_lo, lo) : s_lo; s_hi = is_small ? pk_max_u16(s_hi, hi) : s_hi;
+            m_lo = is_mid ? pk_min_u16(m_lo, lo) : m_lo; m_hi = is_mid ? pk_max_u16(m_hi, hi) : m_hi;
+            my_counts += is_mid ? 1 : ((cls[k] == CLS_HUGE) ? (1 << 16) : 0);
+            n_cull += (in_chunk && !vis) ? 1ull : 0ull;
         }
 
         // the next chunk's attributes start to load now; phases 2 - 5 of this chunk hide their latency
@@ -307,17 +331,19 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         const int mid_total = counts_total & 0xffff, huge_total = counts_total >> 16;
         // reserve contiguous runs in the record lists (one atomic per chunk and list)
         if (tid == 0) {
-            s_base[0] = mid_total ? (long long)atomicAdd(&a.cnt->n_mid, (unsigned long long)mid_total) : 0;
-            s_base[1] = huge_total ? (long long)atomicAdd(&a.cnt->n_huge, (unsigned long long)huge_total) : 0;
-            a.seg_count[c] = mid_total;
-            a.seg_offset[c] = s_base[0];
+            CArgs *ap = KA();
+            Counters *cntp = ap->cnt;
+            s_base[0] = mid_total ? (long long)atomicAdd(&cntp->n_mid, (unsigned long long)mid_total) : 0;
+            s_base[1] = huge_total ? (long long)atomicAdd(&cntp->n_huge, (unsigned long long)huge_total) : 0;
+            ap->seg_count[c] = mid_total;
+            ap->seg_offset[c] = s_base[0];
             if (mid_total) {
                 // covered-pixel bounds [x0, x1] x [y0, y1] stored as (x0, y0, x1 + 1, y1 + 1): kernel M's tile test
                 // bb.x < tile_x1 && bb.z > tile_x0 is then exact for integer tile edges
                 unsigned lo = s_mbb[0][0], hi = s_mbb[0][1];
 #pragma unroll
                 for (int w = 1; w < SWAVES; ++w) { lo = pk_min_u16(lo, s_mbb[w][0]); hi = pk_max_u16(hi, s_mbb[w][1]); }
-                a.seg_bbox[c] = make_float4((float)(lo & 0xffffu), (float)(lo >> 16), (float)((hi & 0xffffu) + 1u), (float)((hi >> 16) + 1u));
+                ap->seg_bbox[c] = make_float4((float)(lo & 0xffffu), (float)(lo >> 16), (float)((hi & 0xffffu) + 1u), (float)((hi >> 16) + 1u));
             }
         }
         __syncthreads();
@@ -331,8 +357,10 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
             unsigned lo = s_mbb[0][0], hi = s_mbb[0][1];
 #pragma unroll
             for (int w = 1; w < SWAVES; ++w) { lo = pk_min_u16(lo, s_mbb[w][0]); hi = pk_max_u16(hi, s_mbb[w][1]); }
-            const int b0 = (int)(lo >> 16) / a.band_h, b1 = (int)(hi >> 16) / a.band_h;
-            for (int b = b0; b <= b1; ++b) a.band_list[(long long)b * a.band_cap + atomicAdd(&a.band_count[b], 1)] = c;
+            CArgs *ap = KA();
+            const int band_h = ap->band_h;
+            const int b0 = (int)(lo >> 16) / band_h, b1 = (int)(hi >> 16) / band_h;
+            for (int b = b0; b <= b1; ++b) ap->band_list[(long long)b * ap->band_cap + atomicAdd(&ap->band_count[b], 1)] = c;
         }
         const int my_mid = my_counts & 0xffff, my_huge = my_counts >> 16;
         const int mid_before = counts_before & 0xffff, huge_before = counts_before >> 16;
@@ -343,9 +371,10 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         // computed once (4 bits each, <= 16 columns), then per pixel row: one ty, the row's LUT values fetched in a batch
         // (LDS latency paid once per row, not per pixel), and per pixel a multiply, a conversion and the ds_add_f64.
         // Loop bounds are wave-uniform (maximum over the lanes), lanes are predicated.
+        const int emit_small = KA()->emit_small, count_frag = KA()->count_frag;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
-            const bool act = (cls[k] == CLS_SMALL) && a.emit_small;
+            const bool act = (cls[k] == CLS_SMALL) && emit_small;
             if (__ballot(act) == 0ull) continue;
             const int nx = act ? (int)(xr[k] >> 16) : 0, ny = act ? (int)(yr[k] >> 16) : 0;
             const int ilo = (int)(xr[k] & 0xffffu), jlo = (int)(yr[k] & 0xffffu);
@@ -399,7 +428,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                     }
                     if ((todo >> lane) & 1ull) latomic_add(win + key, val);
                     n_small += act ? 1 : 0;
-                    if (a.count_frag) n_frag += act ? 1ull : 0ull;
+                    if (count_frag) n_frag += act ? 1ull : 0ull;
                     continue;
                 }
             }
@@ -425,6 +454,9 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                     for (int j = 0; j < 8; ++j) {
                         const int ci = 8 * g + j;
                         if (ci >= maxnx) break;
+#if TSP_S_PAIRMERGE
+                        bool pm_act = false; float pm_val = 0.0f; int pm_key = 0;
+#endif
                         if (ci < nxr) {
                             double *d = wrow + ci;
                             if (MODE == TSP_MODE_RGB) {
@@ -432,48 +464,71 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                                 latomic_add(d + 2 * WIN * WIN, v[j] * w2[k]); latomic_add(d + 3 * WIN * WIN, 1.0f);
                             } else if (v[j] != 0.0f) {      // corner texels are exactly 0: adding +-0 changes nothing
                                 const float val = v[j] * w0[k];
+#if TSP_S_PAIRMERGE
+                                if (WC == 1) { pm_act = true; pm_val = val; pm_key = (int)(d - win); }
+                                else
+#endif
+                                {
                                 latomic_add(d, val);
                                 if (WC > 1) latomic_add(d + WIN * WIN, val * w1[k]);
+                                }
                             }
                         }
+#if TSP_S_PAIRMERGE
+                        if (WC == 1 && MODE != TSP_MODE_RGB) {
+                            // experiment: two neighbouring lanes (2 i, 2 i + 1) that hit the SAME pixel
+                            // in this step are summed first (v_mov_dpp quad_perm:[1,0,3,2]) and the even lane issues one atomic
+                            const int key = pm_act ? pm_key : (-1 - lane);
+                            const int okey = __builtin_amdgcn_mov_dpp(key, 0xb1, 0xf, 0xf, true);
+                            const float oval = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(pm_val), 0xb1, 0xf, 0xf, true));
+                            const bool same = key == okey;
+                            if (pm_act && !(same && (lane & 1))) latomic_add(win + pm_key, same ? pm_val + oval : pm_val);
+                            pm_act = false; pm_val = 0.0f;
+                        }
+#endif
                     }
                 }
             }
             if (act) {
                 ++n_small;
-                if (a.count_frag) n_frag += (unsigned long long)(nx * ny);
+                if (count_frag) n_frag += (unsigned long long)(nx * ny);
             }
         }
 
         // ---- phase 5: append the deferred footprints -----------------------------------------------
         {
+            CArgs *ap = KA();
+            float4 *const mid_geom = ap->mid_geom, *const huge_geom = ap->huge_geom;
+            float *const mid_w = ap->mid_w, *const huge_w = ap->huge_w;
+            const long long mid_capacity = ap->mid_capacity, huge_capacity = ap->huge_capacity;
+            Counters *cntp = ap->cnt;
             long long mpos = mid_base + mid_before + (mid_incl - my_mid);
             long long hpos = huge_base + huge_before + (huge_incl - my_huge);
 #pragma unroll
             for (int k = 0; k < KPT; ++k) {
                 if (cls[k] == CLS_MID) {
-                    if (mpos < a.mid_capacity) {
-                        a.mid_geom[mpos] = make_float4(pcx[k], pcy[k], PP[k], w0[k]);
-                        a.mid_w[mpos * NW] = w1[k];
-                        if (NW == 2) a.mid_w[mpos * NW + 1] = w2[k];
+                    if (mpos < mid_capacity) {
+                        mid_geom[mpos] = make_float4(pcx[k], pcy[k], PP[k], w0[k]);
+                        mid_w[mpos * NW] = w1[k];
+                        if (NW == 2) mid_w[mpos * NW + 1] = w2[k];
                     }
                     ++mpos;
                 } else if (cls[k] == CLS_HUGE) {
-                    if (hpos < a.huge_capacity) {
-                        a.huge_geom[hpos] = make_float4(pcx[k], pcy[k], PP[k], w0[k]);
-                        a.huge_w[hpos * NW] = w1[k];
-                        if (NW == 2) a.huge_w[hpos * NW + 1] = w2[k];
+                    if (hpos < huge_capacity) {
+                        huge_geom[hpos] = make_float4(pcx[k], pcy[k], PP[k], w0[k]);
+                        huge_w[hpos * NW] = w1[k];
+                        if (NW == 2) huge_w[hpos * NW + 1] = w2[k];
                     }
                     ++hpos;
                 } else if (cls[k] == CLS_MEGA) {
                     // the mega records grow downwards from the end of the huge list: one allocation, two cursors
                     // (an overlap with the records growing from the front means overflow: the host sees
                     // n_huge + n_mega > capacity, enlarges the list and replays)
-                    const long long mp = a.huge_capacity - 1 - (long long)atomicAdd(&a.cnt->n_mega, 1ull);
+                    const long long mp = huge_capacity - 1 - (long long)atomicAdd(&cntp->n_mega, 1ull);
                     if (mp >= 0) {
-                        a.huge_geom[mp] = make_float4(pcx[k], pcy[k], PP[k], w0[k]);
-                        a.huge_w[mp * NW] = w1[k];
-                        if (NW == 2) a.huge_w[mp * NW + 1] = w2[k];
+                        huge_geom[mp] = make_float4(pcx[k], pcy[k], PP[k], w0[k]);
+                        huge_w[mp * NW] = w1[k];
+                        if (NW == 2) huge_w[mp * NW + 1] = w2[k];
                     }
                 }
             }
@@ -489,9 +544,10 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         n_frag += __shfl_xor((long long)n_frag, o);
     }
     if (lane == 0) {
-        if (n_small) atomicAdd(&a.cnt->n_small, n_small);
-        if (n_cull) atomicAdd(&a.cnt->n_culled, n_cull);
-        if (n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[0], n_frag); }
+        Counters *cntp = KA()->cnt;
+        if (n_small) atomicAdd(&cntp->n_small, n_small);
+        if (n_cull) atomicAdd(&cntp->n_culled, n_cull);
+        if (n_frag) { atomicAdd(&cntp->n_fragments, n_frag); atomicAdd(&cntp->n_frag_class[0], n_frag); }
     }
 }
 
