@@ -315,14 +315,15 @@ def test_config2_weighted_1e7_full_size(native, mips):
 
 def test_rgb_2048_matches_oracle_at_class_boundaries(native, mips):
     """rgb at R = 2048 against the CPU oracle: a few thousand particles whose footprints sit on and around the class
-    boundaries 11.3 / 13.5 / 22.6 / 45.3 / 64 / 128 / 512 px (kernel S / M / gather kernels), plus a wide spread."""
+    boundaries 11.3 / 13.5 / 16 (small | mid since round 3) / 22.6 / 45.3 / 64 / 128 / 256 / 512 px (kernel S / M / gather
+    kernels), plus a wide spread."""
     from oracle import oracle_c
     R, scale = 2048, 200.0
     M, sf = camera(scale)
     rs = np.random.RandomState(11)
     n = 3000
     pos = (rs.normal(size=(n, 3)) * np.array([60.0, 60.0, 30.0])).astype(np.float32)
-    bounds = np.array([11.3137, 13.5, 22.6274, 45.2548, 64.0, 128.0, 512.0, 700.0])
+    bounds = np.array([11.3137, 13.5, 16.0, 22.6274, 45.2548, 64.0, 128.0, 256.0, 512.0, 700.0])
     P = np.where(rs.uniform(size=n) < 0.6, rs.choice(bounds, size=n) * (1.0 + rs.choice([-1e-6, 0.0, 1e-6, 0.01, -0.01], size=n)),
                  np.exp(rs.uniform(np.log(0.3), np.log(1500.0), size=n)))
     h = (P * scale / (2.0 * R)).astype(np.float32)
