@@ -232,7 +232,10 @@ int tsp_get_stats(tsp_context *ctx, tsp_stats *out);
 /* Options by name.  "count_fragments" (0/1): fragment counting (adds atomics; off by default).  "integrated_px" (0 = off, the
  * default, or >= 128): footprints at least this many pixels wide are drawn by kernel I -- the sparse second differences of
  * the bilinear footprint scattered and the image integrated twice along either axis -- instead of pixel by pixel; exact to
- * ~1e-6 of a footprint's PEAK value rather than of every pixel's own value (tests/test_gpu_integrated.py).  The remaining
+ * ~1e-6 of a footprint's PEAK value rather than of every pixel's own value (tests/test_gpu_integrated.py); a pixel whose
+ * integrated value is below 1e-8 of the render block's largest peak contribution is written as exact 0 (decided on the density
+ * channel for the two-channel modes, on any colour channel for rgb), so footprints more than 1e8 fainter than the block's
+ * heaviest one are invisible where they lie alone, and the threshold is per render block.  The remaining
  * names are tuning and measurement aids of the pipeline (class boundaries, workgroup counts; csrc/tsp_api.hip). */
 int tsp_set_option(tsp_context *ctx, const char *name, int64_t value);
 

@@ -256,3 +256,39 @@ def test_option_range(native, mips):
     ctx.set_option("integrated_px", 128)
     ctx.set_option("integrated_px", 0)
     ctx.close()
+
+
+def test_snap_is_decided_once_per_pixel(native, mips):
+    """Weighted render: wherever kernel I writes the density channel as exact 0 it writes density x quantity as exact 0 too (and
+    nowhere else), even when max |w| and max |w q| of the pass come from different footprints -- the colormap's g / r must
+    never read +-inf at a faint rim.  Switching the option off afterwards releases the second-difference images and the exact
+    kernels take over again."""
+    from oracle import oracle_np
+    R, scale = 512, 100.0
+    M, sf = oracle_np.transform_matrix(np.eye(3), np.zeros(3), scale)
+    # a heavy footprint with a tiny quantity, a light one (1e-7 of the heavy weight) with a huge quantity, far apart
+    P = np.array([300.0, 300.0])
+    h = (P * scale / (2.0 * R)).astype(np.float32)
+    pos = np.array([[-55.0, -55.0, 0.0], [55.0, 55.0, 0.0]], dtype=np.float32)
+    m = np.array([1.0, 1e-7], dtype=np.float32)
+    q = np.array([1e-6, 1e6], dtype=np.float32)
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+    ctx.upload_quantity(q)
+    ctx.render(M, sf, mode=native.MODE_WEIGHTED)
+    exact = ctx.read_image().astype(np.float64)
+    ctx.set_option("integrated_px", 128)
+    ctx.render(M, sf, mode=native.MODE_WEIGHTED)
+    assert ctx.stats()["n_mega"] == 2
+    got = ctx.read_image().astype(np.float64)
+    assert ((got[..., 0] == 0) == (got[..., 1] == 0)).all(), "a pixel keeps or loses BOTH channels"
+    lit = got[..., 0] > 0
+    assert lit.sum() > 20000 and (exact[..., 0][lit] > 0).all()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = got[..., 1][lit] / got[..., 0][lit]
+    assert np.isfinite(ratio).all()
+    ctx.set_option("integrated_px", 0)
+    ctx.render(M, sf, mode=native.MODE_WEIGHTED)
+    assert np.array_equal(ctx.read_image().astype(np.float64), exact) or np.allclose(ctx.read_image(), exact, rtol=1e-6, atol=0)
+    ctx.close()

@@ -458,6 +458,7 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
     ctx->image_is_reduced = false;                             // `image` is this rank's partial image again
     TSP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     TSP_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->ws.int_dirty = false;                                 // kernel I's pass (if any) completed: its D2 is all-zero again
     float ms = 0.f;
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->stats.ms_total = ms;
@@ -714,6 +715,10 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         // clamp-to-edge rim of the square is narrower than a pixel and the edge jumps are no longer pure steps)
         TSP_REQUIRE(value == 0 || (value >= 128 && value <= 1000000), TSP_EINVAL, "integrated_px must be 0 or >= 128, got %lld", (long long)value);
         ctx->integrated_px = (float)value;
+        if (value == 0) {                                      // switched off: give the second-difference images back (nch R^2 doubles)
+            TSP_HIP(hipSetDevice(ctx->device));
+            integrated_release(ctx);
+        }
         return TSP_OK;
     }
     if (!strcmp(name, "mega_variant")) {

@@ -310,28 +310,43 @@ __global__ __launch_bounds__(256) void integrate_cols_partial_kernel(const doubl
 // What is left of the cancelling adds where no footprint (or only its exactly-zero corner) reaches is ~1e-10 of a peak
 // contribution, of either sign: values below 1e-8 of the pass's largest peak contribution count as the exact zero they stand for
 // (no negative dust in a density image: the reference's autorange picks the linear scale on ANY negative value).
-__global__ __launch_bounds__(256) void integrate_cols_apply_kernel(double *__restrict__ D2, int R, const double2 *__restrict__ part,
+// ONE thread takes a pixel column segment in every channel of the pass and decides the snap once per pixel: on the density
+// channel for the two-channel modes (weighted, depth: channel 1 = density x quantity must vanish exactly where the density does,
+// or the colormap's g / r would read +-inf there), on any channel for rgb.
+template <int NCH>
+__global__ __launch_bounds__(256) void integrate_cols_apply_kernel(double *__restrict__ D2, int R, int nseg, const double2 *__restrict__ part,
                                                                    double *__restrict__ img, int C, const unsigned int *__restrict__ wmax,
-                                                                   float peak) {
+                                                                   float peak, bool density_decides) {
     const int i = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y;
     if (i >= R) return;
-    D2 += (size_t)blockIdx.z * R * R;
-    part += (size_t)blockIdx.z * gridDim.y * R;
-    img += blockIdx.z;                       // channel c of the render target
-    const double thr = 1e-8 * (double)peak * (double)__uint_as_float(wmax[blockIdx.z]);
-    double c1 = 0.0, c2 = 0.0;
-    for (int s = 0; s < seg; ++s) {
-        const double2 p = part[(size_t)s * R + i];
-        const int len = min((s + 1) * ISEG, R) - s * ISEG;
-        c2 += p.y + (double)len * c1;
-        c1 += p.x;
+    double thr[NCH], c1[NCH], c2[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        thr[ch] = 1e-8 * (double)peak * (double)__uint_as_float(wmax[ch]);
+        c1[ch] = c2[ch] = 0.0;
+        const double2 *pc = part + (size_t)ch * nseg * R;
+        for (int s = 0; s < seg; ++s) {
+            const double2 p = pc[(size_t)s * R + i];
+            const int len = min((s + 1) * ISEG, R) - s * ISEG;
+            c2[ch] += p.y + (double)len * c1[ch];
+            c1[ch] += p.x;
+        }
     }
     const int j0 = seg * ISEG, j1 = min(j0 + ISEG, R);
     for (int j = j0; j < j1; ++j) {
         const size_t k = (size_t)j * R + i;
-        c1 += D2[k]; c2 += c1;
-        D2[k] = 0.0;
-        if (__builtin_fabs(c2) > thr) gatomic_add(img + k * C, c2);
+        bool keep = false;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            double *d = D2 + (size_t)ch * R * R + k;
+            c1[ch] += *d; c2[ch] += c1[ch];
+            *d = 0.0;
+            if (ch == 0 || !density_decides) keep = keep || (__builtin_fabs(c2[ch]) > thr[ch]);
+        }
+        if (keep) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) gatomic_add(img + k * C + ch, c2[ch]);
+        }
     }
 }
 
@@ -346,10 +361,14 @@ int launch_integrated(tsp_context *ctx, const TileArgs &ta, const float4 *geom, 
     TSP_REQUIRE(integrated_supported(ctx), TSP_ESTATE, "kernel I is not available for this context");
     const int nch = wmode == 0 ? 1 : (wmode == 1 ? 2 : 3);
     const int nseg = (R + ISEG - 1) / ISEG;
+    if (ws.int_dirty) integrated_release(ctx);      // an earlier pass was never seen to finish: its D2 cannot be trusted to be zero
     if (ws.int_channels < nch) {
-        if (ws.int_d2) TSP_HIP(hipFree(ws.int_d2));
-        if (ws.int_part) TSP_HIP(hipFree(ws.int_part));
-        ws.int_d2 = nullptr; ws.int_part = nullptr; ws.int_channels = 0;
+        integrated_release(ctx);
+        const size_t need = (size_t)nch * R * R * sizeof(double) + (size_t)nch * nseg * R * sizeof(double2);
+        size_t free_b = 0, total_b = 0;
+        TSP_HIP(hipMemGetInfo(&free_b, &total_b));
+        TSP_REQUIRE(need < free_b, TSP_ENOMEM, "option integrated_px: the second-difference images of a %d-channel pass at %d^2 need %.1f GB, "
+                    "%.1f GB are free", nch, R, need / 1e9, free_b / 1e9);
         TSP_HIP(hipMalloc((void **)&ws.int_d2, (size_t)nch * R * R * sizeof(double)));
         TSP_HIP(hipMalloc((void **)&ws.int_part, (size_t)nch * nseg * R * sizeof(double2)));
         TSP_HIP(hipMemsetAsync(ws.int_d2, 0, (size_t)nch * R * R * sizeof(double), st));
@@ -380,14 +399,35 @@ int launch_integrated(tsp_context *ctx, const TileArgs &ta, const float4 *geom, 
     const long long runs = (n_records + HDEAL - 1) / HDEAL;
     split = (int)std::min<long long>(split, std::max<long long>((runs + IWAVES - 1) / IWAVES, 1));
     ia.split = split;
+    // From the scatter on, D2 is only all-zero again when the apply kernel has run: any failure in between drops the buffers
+    // (the next pass allocates and clears fresh ones) instead of leaving stale second differences for every later frame.
     hipLaunchKernelGGL(splat_integrated_kernel, dim3(n_bands * ia.nx * split, nch), dim3(IT), smem, st, ia);
-    TSP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(integrate_rows_kernel, dim3(R, nch), dim3(256), 0, st, ws.int_d2, R);
-    hipLaunchKernelGGL(integrate_cols_partial_kernel, dim3((R + 255) / 256, nseg, nch), dim3(256), 0, st, ws.int_d2, R, (double2 *)ws.int_part);
-    hipLaunchKernelGGL(integrate_cols_apply_kernel, dim3((R + 255) / 256, nseg, nch), dim3(256), 0, st, ws.int_d2, R, (const double2 *)ws.int_part,
-                       ctx->image64, ctx->C, ws.int_wmax, ctx->int_peak);
-    TSP_HIP(hipGetLastError());
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(integrate_rows_kernel, dim3(R, nch), dim3(256), 0, st, ws.int_d2, R);
+        hipLaunchKernelGGL(integrate_cols_partial_kernel, dim3((R + 255) / 256, nseg, nch), dim3(256), 0, st, ws.int_d2, R, (double2 *)ws.int_part);
+        const dim3 ag((R + 255) / 256, nseg), ab(256);
+        const bool density_decides = wmode == 1;          // weighted / depth: channel 0 is the density
+        if (nch == 1) hipLaunchKernelGGL(integrate_cols_apply_kernel<1>, ag, ab, 0, st, ws.int_d2, R, nseg, (const double2 *)ws.int_part, ctx->image64, ctx->C, ws.int_wmax, ctx->int_peak, density_decides);
+        else if (nch == 2) hipLaunchKernelGGL(integrate_cols_apply_kernel<2>, ag, ab, 0, st, ws.int_d2, R, nseg, (const double2 *)ws.int_part, ctx->image64, ctx->C, ws.int_wmax, ctx->int_peak, density_decides);
+        else hipLaunchKernelGGL(integrate_cols_apply_kernel<3>, ag, ab, 0, st, ws.int_d2, R, nseg, (const double2 *)ws.int_part, ctx->image64, ctx->C, ws.int_wmax, ctx->int_peak, density_decides);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        ws.int_dirty = true;
+        set_error("kernel I launch failed: %s", hipGetErrorString(e));
+        return TSP_EHIP;
+    }
+    ws.int_dirty = true;        // cleared by tsp_render once the stream has drained without error
     return TSP_OK;
+}
+
+// Free the second-difference images (option switched off, or their content is not known to be zero any more).
+void integrated_release(tsp_context *ctx) {
+    Workspace &ws = ctx->ws;
+    if (ws.int_d2) (void)hipFree(ws.int_d2);
+    if (ws.int_part) (void)hipFree(ws.int_part);
+    ws.int_d2 = nullptr; ws.int_part = nullptr; ws.int_channels = 0; ws.int_dirty = false;
 }
 
 // The tables of kernel I, float64, one allocation (offsets INT_O_*):

@@ -72,6 +72,7 @@ struct Workspace {     // per-context scratch of the three-class pipeline (grown
     int *count_band = nullptr;          // rgb: per (64-row band, column) sums of its row-scanned form
     double *int_d2 = nullptr;           // kernel I: [int_channels] R x R second-difference images (zero between render blocks)
     int int_channels = 0;
+    bool int_dirty = false;             // kernel I: a pass was issued and has not been seen to complete (D2 may hold stale second differences)
     unsigned int *int_wmax = nullptr;   // kernel I: per channel, the largest |weight| of the pass (float bits)
     void *int_part = nullptr;           // kernel I: per (32-row segment, column) partial sums of the column pass
 };
@@ -176,5 +177,6 @@ constexpr int INT_O_PA = 66 * INT_S0_STRIDE, INT_O_PB = INT_O_PA + 66 * INT_S0_S
 constexpr int INT_O_PBY = INT_O_PAY + 65 * INT_S0_STRIDE, INT_O_M = INT_O_PBY + 65 * INT_S0_STRIDE;
 constexpr int INT_TABLE_DOUBLES = INT_O_M + 65 * 65 * 4;
 bool integrated_supported(const tsp_context *ctx);
+void integrated_release(tsp_context *ctx);
 void integrated_tables(const float *mip0, std::vector<double> &out);
 }  // namespace tsp
