@@ -261,6 +261,39 @@ int tsp_comm_init(tsp_context *ctx, int n_ranks, int rank, const char *id);
 int tsp_comm_reduce_image(tsp_context *ctx, int root, double *gpu_ms_out);
 int tsp_comm_destroy(tsp_context *ctx);
 
+/* Several GPUs of one node behind ONE handle (SURVEY.md section 8b sketched `tsp_create(n_devices, device_ids, ...)`; the
+ * reference has no counterpart -- its SplitBuffers, src/topsy/split_buffers.py:26-38,78-116, cuts one device's buffers the same
+ * way).  A group is n_devices ordinary contexts plus the host-thread choreography: uploads are cut into the contiguous index
+ * ranges [g N / G, (g + 1) N / G), tsp_group_render intersects the block's (start, len) ranges with every shard and runs the
+ * G tsp_render calls concurrently (returns the slowest shard's GPU time), and tsp_group_end_frame is the frame's ONE sum-reduce
+ * of the float32 image onto context 0 -- RCCL over xGMI when the device ids are distinct, a read-back / add / write-back through
+ * the host when two contexts share a device (RCCL refuses that; single-GPU test boxes).  Everything that looks at the finished
+ * frame (tsp_read_image, tsp_colormap_*, tsp_content_*, tsp_tile_periodic) is called on tsp_group_context(group, 0) after
+ * tsp_group_end_frame; per-shard state can be inspected through tsp_group_context(group, g).  The reduce contract of
+ * tsp_comm_reduce_image holds: end_frame reduces at most once per rendered frame, and a later tsp_group_render -- a REFINE
+ * block with clear = 0 included -- continues from every shard's own float64 accumulator.  Calls on one group must be
+ * serialised by the caller.  tsp_group_get_stats: counters summed over the shards, times of the slowest shard. */
+typedef struct tsp_group tsp_group;
+int tsp_group_create(int n_devices, const int *device_ids, int resolution, int n_channels, tsp_group **out);
+void tsp_group_destroy(tsp_group *group);
+int tsp_group_size(tsp_group *group);
+tsp_context *tsp_group_context(tsp_group *group, int index);
+int tsp_group_uses_rccl(tsp_group *group);
+int tsp_group_set_kernel_mips(tsp_group *group, const float *lut, int n0, int n_levels);
+int tsp_group_upload_particles(tsp_group *group, int64_t n, const float *x, const float *y, const float *z, const float *h,
+                               const float *mass);
+int tsp_group_upload_quantity(tsp_group *group, const float *q);
+int tsp_group_upload_rgb(tsp_group *group, const float *r, const float *g, const float *b);
+int tsp_group_generate_synthetic(tsp_group *group, int64_t n_total, int64_t first, int64_t count, uint64_t seed, float h_cap,
+                                 int with_quantity, int with_rgb);
+int tsp_group_reorder_spatial(tsp_group *group, int n_strata, uint64_t seed);
+int64_t tsp_group_num_particles(tsp_group *group);
+int tsp_group_set_option(tsp_group *group, const char *name, int64_t value);
+int tsp_group_render(tsp_group *group, const float *M, float scale_factor, const int64_t *starts, const int64_t *lens,
+                     int n_ranges, int clear, int mode, int flags, double *gpu_ms_out);
+int tsp_group_end_frame(tsp_group *group, double *ms_out);
+int tsp_group_get_stats(tsp_group *group, tsp_stats *out);
+
 #ifdef __cplusplus
 }
 #endif

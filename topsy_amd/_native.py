@@ -91,6 +91,25 @@ SIGNATURES = {
     "tsp_comm_init": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
     "tsp_comm_reduce_image": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "tsp_comm_destroy": (ctypes.c_int, [_ctx]),
+    # several GPUs behind one handle (C clients; the Python layer's own driver is multigpu.MultiGpuContext)
+    "tsp_group_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.POINTER(_ctx)]),
+    "tsp_group_destroy": (None, [_ctx]),
+    "tsp_group_size": (ctypes.c_int, [_ctx]),
+    "tsp_group_context": (_ctx, [_ctx, ctypes.c_int]),
+    "tsp_group_uses_rccl": (ctypes.c_int, [_ctx]),
+    "tsp_group_set_kernel_mips": (ctypes.c_int, [_ctx, _fp, ctypes.c_int, ctypes.c_int]),
+    "tsp_group_upload_particles": (ctypes.c_int, [_ctx, ctypes.c_int64, _fp, _fp, _fp, _fp, _fp]),
+    "tsp_group_upload_quantity": (ctypes.c_int, [_ctx, _fp]),
+    "tsp_group_upload_rgb": (ctypes.c_int, [_ctx, _fp, _fp, _fp]),
+    "tsp_group_generate_synthetic": (ctypes.c_int, [_ctx, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64,
+                                                    ctypes.c_float, ctypes.c_int, ctypes.c_int]),
+    "tsp_group_reorder_spatial": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_uint64]),
+    "tsp_group_num_particles": (ctypes.c_int64, [_ctx]),
+    "tsp_group_set_option": (ctypes.c_int, [_ctx, ctypes.c_char_p, ctypes.c_int64]),
+    "tsp_group_render": (ctypes.c_int, [_ctx, _fp, ctypes.c_float, _i64p, _i64p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
+    "tsp_group_end_frame": (ctypes.c_int, [_ctx, ctypes.POINTER(ctypes.c_double)]),
+    "tsp_group_get_stats": (ctypes.c_int, [_ctx, ctypes.POINTER(Stats)]),
 }
 
 _lib = None
@@ -411,3 +430,105 @@ class Context:
         ms = ctypes.c_double(0.0)
         _check(self._lib.tsp_comm_reduce_image(self._h, root, ctypes.byref(ms)))
         return ms.value
+
+
+class Group:
+    """ctypes view of the C-level device group (tsp_group_*, include/topsy_splat.h): what a C client uses to put several
+    GPUs behind one handle.  The product's own multi-GPU driver is multigpu.MultiGpuContext; this class exists so that the
+    tests exercise the C entry points.  `root` is a borrowed Context over tsp_group_context(group, 0)."""
+
+    def __init__(self, resolution, n_channels, device_ids):
+        self._lib = load_library()
+        ids = (ctypes.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        h = _ctx()
+        _check(self._lib.tsp_group_create(len(device_ids), ids, int(resolution), int(n_channels), ctypes.byref(h)))
+        self._g = h
+        self.resolution, self.n_channels = int(resolution), int(n_channels)
+        self.root = self.member(0)
+
+    def member(self, index):
+        h = self._lib.tsp_group_context(self._g, int(index))
+        if not h:
+            raise IndexError(index)
+        c = Context.__new__(Context)
+        c._lib = self._lib
+        c._h = _ctx(h)
+        c.close = lambda: None           # borrowed: the group destroys its contexts
+        c.resolution, c.n_channels, c.device_id, c.active_channels = self.resolution, self.n_channels, -1, 2
+        return c
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self.root._h = None
+            self._lib.tsp_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return self._lib.tsp_group_size(self._g)
+
+    @property
+    def uses_rccl(self):
+        return bool(self._lib.tsp_group_uses_rccl(self._g))
+
+    @property
+    def num_particles(self):
+        return self._lib.tsp_group_num_particles(self._g)
+
+    def set_kernel_mips(self, mips, n0=64, n_levels=4):
+        m = _f32(mips, None, "mips")
+        _check(self._lib.tsp_group_set_kernel_mips(self._g, _ptr(m), n0, n_levels))
+
+    def upload_particles(self, x, y, z, h, mass=None):
+        n = len(x)
+        arrs = [_f32(a, n, nm) for a, nm in ((x, "x"), (y, "y"), (z, "z"), (h, "h"))]
+        m = None if mass is None else _f32(mass, n, "mass")
+        _check(self._lib.tsp_group_upload_particles(self._g, n, *[_ptr(a) for a in arrs], None if m is None else _ptr(m)))
+
+    def upload_quantity(self, q):
+        qa = None if q is None else _f32(q, self.num_particles, "q")
+        _check(self._lib.tsp_group_upload_quantity(self._g, None if qa is None else _ptr(qa)))
+
+    def generate_synthetic(self, n_total, first=0, count=None, seed=1337, h_cap=0.0, with_quantity=False, with_rgb=False):
+        count = n_total - first if count is None else count
+        _check(self._lib.tsp_group_generate_synthetic(self._g, int(n_total), int(first), int(count), int(seed), float(h_cap),
+                                                      int(with_quantity), int(with_rgb)))
+
+    def reorder_spatial(self, n_strata=1, seed=1337):
+        _check(self._lib.tsp_group_reorder_spatial(self._g, int(n_strata), int(seed)))
+
+    def set_option(self, name, value):
+        _check(self._lib.tsp_group_set_option(self._g, name.encode(), int(value)))
+
+    def render(self, matrix, scale_factor, starts=None, lens=None, clear=True, mode=MODE_WEIGHTED, flags=PIPE_DEFAULT):
+        M = _f32(np.asarray(matrix, dtype=np.float32).reshape(16), 16, "matrix")
+        ms = ctypes.c_double(0.0)
+        if starts is None:
+            sp = lp = None
+            nr = 0
+        else:
+            s = np.ascontiguousarray(starts, dtype=np.int64)
+            l = np.ascontiguousarray(lens, dtype=np.int64)
+            if len(s) == 0:
+                s, l = np.zeros(1, dtype=np.int64), np.zeros(1, dtype=np.int64)
+            sp, lp, nr = s.ctypes.data_as(_i64p), l.ctypes.data_as(_i64p), len(s)
+        _check(self._lib.tsp_group_render(self._g, _ptr(M), float(scale_factor), sp, lp, nr, int(bool(clear)), int(mode), int(flags),
+                                          ctypes.byref(ms)))
+        self.root.active_channels = 4 if mode == MODE_RGB else 2
+        return ms.value
+
+    def end_frame(self):
+        ms = ctypes.c_double(0.0)
+        _check(self._lib.tsp_group_end_frame(self._g, ctypes.byref(ms)))
+        return ms.value
+
+    def stats(self):
+        st = Stats()
+        _check(self._lib.tsp_group_get_stats(self._g, ctypes.byref(st)))
+        return st.as_dict()
