@@ -104,6 +104,8 @@ def profile_entry(prof, kernel, mode):
         a = [x.strip() for x in args.rstrip(">").split(",")]
         if not a or a[0] != str(tmpl_mode):
             continue
+        if a[-1] == "true":          # the instantiation with fragment counting compiled in: the one counting frame, not the timed ones
+            continue
         if first is not None and (len(a) < 2 or a[1] != first):
             continue
         hits.append((k, v))
@@ -277,7 +279,7 @@ def main():
         dom_ms = parts[dom]
         dom = {"stream": "splat_stream_kernel", "mid": "splat_mid_kernel",
                "mega": "splat_mega64_kernel" if args.mode == "density" else "splat_mega_kernel",
-               "huge": "splat_huge_kernel" if args.mode == "rgb" else "splat_huge2_kernel"}[dom]
+               "huge": "splat_huge2_kernel"}[dom]
     bytes_per_launch = B_ALG[args.mode] * n_per
     achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     stream_ms = means["stream"] if means["stream"] > 0 else means["total"]

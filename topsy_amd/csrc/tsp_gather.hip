@@ -339,7 +339,8 @@ constexpr int PT_STRIDE = 65;        // floats per row: 64 + one clamp-to-edge c
 
 constexpr int H2T = 256;             // threads per workgroup of kernel H2: 4 waves = 2 x 2 strips sharing one pair table
 
-template <int MODE, int NACC, int W, int HR, int OCC>
+// CNT: fragment counting compiled in (tsp_set_option "count_fragments"); the product instantiation carries none of it
+template <int MODE, int NACC, int W, int HR, int OCC, bool CNT>
 __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
                 // density: the particle weight rides on the column factors, so a pixel costs two FMAs
                 fxs[w] = (NACC == 1) ? fr * wq.x : fr;
                 gxs[w] = (NACC == 1) ? (cv - fr) * wq.x : (cv - fr);
-                if (a.count_frag) ncov_x += (cv != 0.0f);
+                if (CNT) ncov_x += (cv != 0.0f);
             }
             float top[W], bot[W];
             float2 nxt[W];                              // prefetched pair of texel row r + 2
@@ -568,9 +569,9 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             TSP_H2_GROUP(4) TSP_H2_GROUP(5) TSP_H2_GROUP(6) TSP_H2_GROUP(7)
 #undef TSP_H2_GROUP
 #undef TSP_H2_ROW
-            if (a.count_frag) n_frag += (unsigned long long)(ncov_x * __popc(covmask));
+            if (CNT) n_frag += (unsigned long long)(ncov_x * __popc(covmask));
 #ifdef TSP_H2_DEBUG      // analysis build: (footprint, strip) pairs, covered rows and texel-row changes instead of the S / M / H3 fragment counts
-            if (a.count_frag && lane == 0) {
+            if (CNT && lane == 0) {
                 atomicAdd(&a.cnt->n_frag_class[0], 1ull);
                 atomicAdd(&a.cnt->n_frag_class[1], (unsigned long long)__popc(covmask));
                 atomicAdd(&a.cnt->n_frag_class[3], (unsigned long long)__popc(chgmask));
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             }
     }
     } while (run0 * usplit < n_runs);
-    if (a.count_frag) {
+    if (CNT) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
         if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[2], n_frag); }
     }
@@ -625,7 +626,8 @@ static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
     split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
     ta.split = split;
     ta.tiles_x = htiles_x;
-    hipLaunchKernelGGL((splat_huge2_kernel<MODE, NACC, W, HR, OCC>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
+    if (ta.count_frag) hipLaunchKernelGGL((splat_huge2_kernel<MODE, NACC, W, HR, OCC, true>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
+    else hipLaunchKernelGGL((splat_huge2_kernel<MODE, NACC, W, HR, OCC, false>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
     TSP_HIP(hipGetLastError());
     return TSP_OK;
 }
@@ -646,7 +648,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // NB = 32-column blocks per wave strip (strip = 32 NB columns x 32 rows): the row factors and the A operand of a k-step
 // are shared by the NB column blocks, so wider strips spend fewer VALU instructions per pixel (the kernel is VALU-bound:
 // ~60 preparation instructions per footprint and strip against 2 NB MFMAs per k-step)
-template <int MODE, int NACC, int NB, int OCC>
+template <int MODE, int NACC, int NB, int OCC, bool CNT>
 __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
@@ -759,7 +761,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
                 rel = r - r0;
                 const int kmax = __builtin_amdgcn_readlane(rel, last_row);   // texel rows are monotone down the strip
                 nsteps = (kmax + 3) >> 1;                             // texel rows r0 .. r0 + kmax + 1, two per MFMA
-                if (a.count_frag) {
+                if (CNT) {
                     const unsigned long long rows = __ballot(cv != 0.0f && kh == 0);
                     int ncx = 0;
 #pragma unroll
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
     }
     flush();
     } while (run0 * usplit < n_runs);
-    if (a.count_frag) {
+    if (CNT) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
         if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[3], n_frag); }
     }
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega_kernel(TileArgs a) {
 
 // Density-only variant of kernel H3 with 64 x 64 wave strips (two row blocks of two column blocks): the column factors and
 // the footprint's parameters are prepared once for 4096 pixels instead of 2048 (experiment, `mega_variant` = 1).
-template <int MODE, int OCC>
+template <int MODE, int OCC, bool CNT>
 __global__ __launch_bounds__(H2T, OCC) void splat_mega64_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NB = 2, NR = 2;
@@ -955,7 +957,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega64_kernel(TileArgs a) {
                 caddr[b] = ((int)f0) * 4;
                 fxs[b] = fr * w0;
                 gxs[b] = (cv - fr) * w0;
-                if (a.count_frag) ncx += (cv != 0.0f) ? 1 : 0;
+                if (CNT) ncx += (cv != 0.0f) ? 1 : 0;
             }
 #pragma unroll
             for (int rb = 0; rb < NR; ++rb) {
@@ -973,7 +975,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega64_kernel(TileArgs a) {
                 const int rel = r - r0;
                 const int kmax = __builtin_amdgcn_readlane(rel, last_row[rb]);
                 const int nsteps = (kmax + 3) >> 1;
-                if (a.count_frag && kh == 0) n_frag += (unsigned long long)(ncx * __popcll(rows));
+                if (CNT && kh == 0) n_frag += (unsigned long long)(ncx * __popcll(rows));
                 int rowoff = (r0 + kh) * (PT_STRIDE * 4);
                 int kk = kh;
                 for (int m = 0; m < nsteps; ++m) {
@@ -992,7 +994,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega64_kernel(TileArgs a) {
     }
     flush();
     } while (run0 * usplit < n_runs);
-    if (a.count_frag) {
+    if (CNT) {
         for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
         if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[3], n_frag); }
     }
@@ -1010,7 +1012,8 @@ static int launch_mega64(tsp_context *ctx, TileArgs ta, long long n_huge) {
     split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
     ta.split = split;
     ta.tiles_x = htiles_x;
-    hipLaunchKernelGGL((splat_mega64_kernel<MODE, OCC>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
+    if (ta.count_frag) hipLaunchKernelGGL((splat_mega64_kernel<MODE, OCC, true>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
+    else hipLaunchKernelGGL((splat_mega64_kernel<MODE, OCC, false>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
     TSP_HIP(hipGetLastError());
     return TSP_OK;
 }
@@ -1027,7 +1030,8 @@ static int launch_mega(tsp_context *ctx, TileArgs ta, long long n_huge) {
     split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
     ta.split = split;
     ta.tiles_x = htiles_x;
-    hipLaunchKernelGGL((splat_mega_kernel<MODE, NACC, NB, OCC>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
+    if (ta.count_frag) hipLaunchKernelGGL((splat_mega_kernel<MODE, NACC, NB, OCC, true>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
+    else hipLaunchKernelGGL((splat_mega_kernel<MODE, NACC, NB, OCC, false>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
     TSP_HIP(hipGetLastError());
     return TSP_OK;
 }
