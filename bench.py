@@ -70,6 +70,10 @@ def parse():
     ap.add_argument("--no-reorder", action="store_true")
     ap.add_argument("--integrated-px", type=int, default=0,
                     help="option integrated_px of the library (kernel I for footprints at least this wide); 0 = the default path")
+    ap.add_argument("--shared-device-dry-run", action="store_true",
+                    help="harness test on a 1-GPU box: every rank uses device 0 and the image reduce is skipped (RCCL refuses two "
+                         "ranks on one device), so the launcher logic of an N > 1 run -- rendezvous, shards, barriers, the "
+                         "max-over-ranks time, the JSON line -- can be exercised; the line is marked and its value means nothing")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline frames: no extra configurations, no CPU baseline (what the profiler runs, so "
                          "that every kernel instance in a profile belongs to the headline workload)")
@@ -191,12 +195,15 @@ def main():
     mips = kernel_lut.kernel_mips()
     h_cap = args.h_cap_px * args.scale / (2.0 * R) if args.h_cap_px > 0 else 0.0
     t_setup = time.time()
+    if args.shared_device_dry_run:
+        local_rank = 0
     ctx = make_context(_native, mips, R, channels, local_rank, n_total, first, n_per, args, h_cap, args.mode)
     t_setup = time.time() - t_setup
     if args.integrated_px:
         ctx.set_option("integrated_px", args.integrated_px)
 
-    if world > 1:
+    use_comm = world > 1 and not args.shared_device_dry_run
+    if use_comm:
         ids = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(world, rank, ids[0])
@@ -215,7 +222,7 @@ def main():
             st = ctx.stats()
             for k in KERNELS + ("total",):
                 kernel_ms[k].append(st["ms_" + k])
-        if world > 1:
+        if use_comm:
             ms = ctx.comm_reduce_image(root=0)
             if record:
                 kernel_ms["reduce"].append(ms)
@@ -338,6 +345,8 @@ def main():
         "kernel_ms": means,
         "setup_s": t_setup,
     }
+    if args.shared_device_dry_run:
+        result["dry_run"] = "ranks shared device 0 and no image reduce ran: harness test only, `value` is not a measurement"
     if world > 1:
         result["roofline_fragment"]["note_n_gpus"] = (f"per GPU: 1/{world} of the frame's fragments against rank 0's kernel times "
                                                       "and the step time")
