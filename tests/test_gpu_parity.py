@@ -502,6 +502,24 @@ def test_gather_kernel_class_boundaries(native, mips, mode, R):
         wide = int((h.astype(np.float64) * 2.0 * R / scale >= p_mega).sum())
         assert 0 < st["n_mega"] <= wide             # (some of them are off-screen or outside the z-slab)
         assert st["n_mega"] > wide // 3
+    # the kernel variants that large record counts (or options) select, same scene, exact culling on
+    extra = {"rgb": [("rgb_mega_variant", 1), ("rgb_mega_variant", 3), ("rgb_mega_variant", 4), ("huge_variant", 0)],
+             "weighted": [("mega_variant", 4), ("mega_variant", 3), ("mega_variant", 5), ("huge_variant", 4)],
+             "depth": [("mega_variant", 4), ("mega_variant", 5)]}[mode]
+    for name, value in extra:
+        ctx.set_option(name, value)
+        if mode == "rgb":
+            ctx.render(M, sf, mode=native.MODE_RGB)
+            got = ctx.read_image()
+            assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=0), (name, value)
+            assert np.array_equal(got[..., 3], want[..., 3]), (name, value)
+        elif mode == "depth":
+            ctx.render(M, sf, mode=native.MODE_DEPTH)
+            assert np.allclose(ctx.read_image(), want, rtol=1e-5, atol=0), (name, value)
+        else:
+            ctx.render(M, sf, mode=native.MODE_WEIGHTED)
+            check_2ch(ctx.read_image(), want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
+        ctx.set_option(name, {"rgb_mega_variant": 2, "mega_variant": 0, "huge_variant": 1}[name])
     ctx.close()
 
 
@@ -538,6 +556,21 @@ def test_gather_kernels_fold_their_accumulators(native, mips):
     ctx.render(M, sf)
     assert ctx.stats()["n_mega"] == 0
     assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0)
+    # H2's strip shapes / occupancies: 64x32 strips at 4 and 6 waves per SIMD (7 = what large record counts select since
+    # round 4, row factors fetched group by group), 64x16 at 7 / 8 / 6
+    for variant in (2, 7, 4, 5, 6):
+        ctx.set_option("huge_variant", variant)
+        ctx.render(M, sf)
+        assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0), variant
+    ctx.set_option("p_mega_px", 512)
+    ctx.set_option("huge_variant", 7)
+    for variant in (1, 2, 4):                  # ... combined with H3 on 64x32 strips at 4 / 5 waves and on 64x64 strips
+        ctx.set_option("mega_variant", variant)
+        ctx.render(M, sf)
+        assert ctx.stats()["n_mega"] == n // 2
+        assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0), variant
+    ctx.set_option("mega_variant", 0)
+    ctx.set_option("p_mega_px", 0)
     ctx.set_option("huge_variant", 0)          # and through the round-1 kernel H
     ctx.render(M, sf)
     assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0)

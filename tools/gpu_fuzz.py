@@ -4,6 +4,13 @@ import numpy as np
 from oracle import oracle_np, oracle_c
 from topsy_amd import _native as native, kernel_lut
 mips = kernel_lut.kernel_mips()
+# TSP_FUZZ_OPTS="huge_variant=7 mega_variant=1": library options forced on every context (kernel variants the record counts of
+# these small scenes would not select)
+OPTS = [kv.split("=") for kv in os.environ.get("TSP_FUZZ_OPTS", "").split()]
+def make_ctx(R, C):
+    c = native.Context(R, C); c.set_kernel_mips(mips)
+    for k, v in OPTS: c.set_option(k, int(v))
+    return c
 def rot(a, b):
     ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
     return np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]]) @ np.array([[1, 0, 0], [0, cb, -sb], [0, sb, cb]])
@@ -28,7 +35,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     if MODE != "weighted":
         rgb = rs.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32)
         md = native.MODE_RGB if MODE == "rgb" else native.MODE_DEPTH
-        ctx = native.Context(R, 4 if MODE == "rgb" else 2); ctx.set_kernel_mips(mips)
+        ctx = make_ctx(R, 4 if MODE == "rgb" else 2)
         ctx.upload_particles(x, y, z, h, None if MODE == "rgb" else m)
         if MODE == "rgb":
             ctx.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
@@ -48,7 +55,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             print("FAIL", MODE, "seed", seed, "R", R, "scale", scale, "n", n, "hmax", hmax)
         ctx.close()
         continue
-    ctx = native.Context(R, 2); ctx.set_kernel_mips(mips)
+    ctx = make_ctx(R, 2)
     ctx.upload_particles(x, y, z, h, m); ctx.upload_quantity(q)
     ctx.set_option("count_fragments", 1)
     ctx.render(M, sf)
