@@ -869,7 +869,10 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mega64_kernel(TileArgs a) {
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) pxc[b] = (sx + 32 * b + li < R) ? (float)(sx + 32 * b + li) + 0.5f : __builtin_inff();
-    constexpr int FOLD_EVERY = TSP_FOLD_EVERY;
+    // a wave of this kernel sees ~500 footprints per launch (the mega list is short and split over >= 96 workgroups per tile), so
+    // with 1024 per segment nearly every wave flushes ONCE, at the end: the float64 flush atomics are this kernel's only HBM write
+    // traffic (2.5 GB per launch at 512, profiles/round4a); float32 sums of <= 1087 terms: ~2e-6 relative at worst
+    constexpr int FOLD_EVERY = 2 * TSP_FOLD_EVERY;
     f32x16 acc[NR][NB];
 #pragma unroll
     for (int rb = 0; rb < NR; ++rb)
