@@ -148,6 +148,9 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
     int wox = 0, woy = 0;
     int dx0 = WIN, dy0 = WIN, dx1 = -1, dy1 = -1;
     unsigned long long n_small = 0, n_cull = 0, n_frag = 0;
+#ifdef TSP_S_DEBUG
+    unsigned long long dbg_slots = 0;
+#endif
 
 
     auto flush = [&]() {
@@ -454,6 +457,9 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                     for (int j = 0; j < 8; ++j) {
                         const int ci = 8 * g + j;
                         if (ci >= maxnx) break;
+#ifdef TSP_S_DEBUG       // analysis build: lane slots the raster loop spends (64 per executed pixel step), reported as the M fragment count
+                        if (count_frag && lane == 0) dbg_slots += 64ull;
+#endif
 #if TSP_S_PAIRMERGE
                         bool pm_act = false; float pm_val = 0.0f; int pm_key = 0;
 #endif
@@ -548,6 +554,9 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         if (n_small) atomicAdd(&cntp->n_small, n_small);
         if (n_cull) atomicAdd(&cntp->n_culled, n_cull);
         if (n_frag) { atomicAdd(&cntp->n_fragments, n_frag); atomicAdd(&cntp->n_frag_class[0], n_frag); }
+#ifdef TSP_S_DEBUG
+        if (dbg_slots) atomicAdd(&cntp->n_frag_class[1], dbg_slots);
+#endif
     }
 }
 
