@@ -453,14 +453,15 @@ def test_randomised_views(native, mips, seed):
 def test_gather_kernel_class_boundaries(native, mips, mode, R):
     """Footprints right at the class boundaries of the tile-gather kernels -- 64 px (nearest mip 0 -> bilinear: kernel M
     -> H2; a texel row per pixel row, the one case where rounding may skip a texel row) and p_mega (H2 / H -> H3 on the
-    matrix cores: 512 px for density, 256 px for the two-channel modes, 128 px for rgb) -- at arbitrary sub-pixel centres,
+    matrix cores: 768 px for density, 384 px for the two-channel modes, 128 px for rgb) -- at arbitrary sub-pixel centres,
     partly off-screen, against the oracle: image within 1e-5 and the exact fragment count.  R = 200 leaves partial tiles
     and strips on both axes."""
     from oracle import oracle_np
     scale = 100.0
     M, sf = oracle_np.transform_matrix(_rot(0.0, 0.0), np.zeros(3), scale)
     widths = np.array([63.99, 64.0, 64.0001, 64.001, 64.5, 65.0, 90.0, 127.9, 127.999, 128.0, 128.001, 200.3, 255.9, 255.999, 256.0,
-                       256.001, 300.0, 511.9, 511.999, 512.0, 512.001, 700.0, 1023.0, 1024.0, 3000.0, 20000.0], dtype=np.float64)
+                       256.001, 300.0, 383.999, 384.0, 384.001, 511.9, 511.999, 512.0, 512.001, 700.0, 767.999, 768.0, 768.001, 1023.0, 1024.0, 3000.0,
+                       20000.0], dtype=np.float64)
     rs = np.random.RandomState(77)
     reps = 6
     P = np.repeat(widths, reps)
@@ -498,7 +499,7 @@ def test_gather_kernel_class_boundaries(native, mips, mode, R):
         st = ctx.stats()
         if count:
             assert st["n_fragments"] == nfrag
-        p_mega = 128.0 if mode == "rgb" else 256.0          # (weighted with a quantity and depth are two-channel renders)
+        p_mega = 128.0 if mode == "rgb" else 384.0          # (weighted with a quantity and depth are two-channel renders)
         wide = int((h.astype(np.float64) * 2.0 * R / scale >= p_mega).sum())
         assert 0 < st["n_mega"] <= wide             # (some of them are off-screen or outside the z-slab)
         assert st["n_mega"] > wide // 3
@@ -541,6 +542,7 @@ def test_gather_kernels_fold_their_accumulators(native, mips):
     ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
     ctx.set_option("huge_split", 1)
     ctx.set_option("mega_split", 1)
+    ctx.set_option("p_mega_px", 512)           # the class split this scene was laid out for (default since round 4: 768 px)
     ctx.render(M, sf)
     got = ctx.read_image()
     assert ctx.stats()["n_mega"] == n // 2 and ctx.stats()["n_huge"] == n

@@ -315,7 +315,7 @@ def test_config2_weighted_1e7_full_size(native, mips):
 
 def test_rgb_2048_matches_oracle_at_class_boundaries(native, mips):
     """rgb at R = 2048 against the CPU oracle: a few thousand particles whose footprints sit on and around the class
-    boundaries 11.3 / 13.5 / 16 (small | mid since round 3) / 22.6 / 45.3 / 64 / 128 / 256 / 512 px (kernel S / M / gather
+    boundaries 11.3 / 13.5 / 16 (small | mid since round 3) / 22.6 / 45.3 / 64 / 128 / 256 / 384 / 512 / 768 px (kernel S / M / gather
     kernels), plus a wide spread."""
     from oracle import oracle_c
     R, scale = 2048, 200.0
@@ -323,7 +323,7 @@ def test_rgb_2048_matches_oracle_at_class_boundaries(native, mips):
     rs = np.random.RandomState(11)
     n = 3000
     pos = (rs.normal(size=(n, 3)) * np.array([60.0, 60.0, 30.0])).astype(np.float32)
-    bounds = np.array([11.3137, 13.5, 16.0, 22.6274, 45.2548, 64.0, 128.0, 256.0, 512.0, 700.0])
+    bounds = np.array([11.3137, 13.5, 16.0, 22.6274, 45.2548, 64.0, 128.0, 256.0, 384.0, 512.0, 700.0, 768.0])
     P = np.where(rs.uniform(size=n) < 0.6, rs.choice(bounds, size=n) * (1.0 + rs.choice([-1e-6, 0.0, 1e-6, 0.01, -0.01], size=n)),
                  np.exp(rs.uniform(np.log(0.3), np.log(1500.0), size=n)))
     h = (P * scale / (2.0 * R)).astype(np.float32)
@@ -361,6 +361,7 @@ def test_record_list_overflow_replay_with_mega_records(native, mips, label, h_va
         c2.set_kernel_mips(mips)
         c2.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
         c2.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
+        c2.set_option("p_mega_px", 512)          # (the default moved to 768 px in round 4; 614-px footprints must stay mega records here)
         c2.render(M, sf, mode=mode)              # first frame: overflow -> grow -> replay
         st = c2.stats()
         a = c2.read_image().astype(np.float64)
@@ -368,7 +369,7 @@ def test_record_list_overflow_replay_with_mega_records(native, mips, label, h_va
         assert st["n_mega"] > 0
         if mode == native.MODE_RGB:              # rgb: kernel H3 from 128 px, so both widths are mega records
             assert st["n_mega"] == st["n_huge"]
-        else:                                    # density: from 512 px
+        else:                                    # density: from p_mega_px = 512 px here
             assert (st["n_mega"] == st["n_huge"]) == (label == "all-mega")
         assert st["n_huge"] + st["n_culled"] == n
         c2.render(M, sf, mode=mode)              # second frame: the lists are large enough now
