@@ -7,6 +7,7 @@
 //   kernel H2  splat_huge2_kernel  row-uniform gather, 64 px <= P < p_mega
 //   kernel H3  splat_mega_kernel   outer products on the matrix cores, P >= p_mega
 #include <algorithm>
+#include <type_traits>
 
 #include "tsp_pipeline.h"
 
@@ -346,7 +347,8 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
     constexpr int TW = 2 * 64 * W, TH = 2 * HR;            // tile: 2 x 2 wave strips of (64 W) x HR pixels
     constexpr int NG = HR / 4;                             // row groups (one quad of lanes carries a group's factors)
-    static_assert(HR == 16 || HR == 32, "rows per wave strip");
+    static_assert(HR == 16 || HR == 32 || HR == 64, "rows per wave strip");
+    typedef typename std::conditional<HR == 64, unsigned long long, unsigned>::type mask_t;     // one bit per pixel row of the strip
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // level-0 kernel image with clamp-to-edge padding: texels (r, c) and (r, c + 1) of an x-interpolation are adjacent
     // dwords, fetched by one ds_read2_b32
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
                 if (NACC >= 3) asm volatile("v_mov_b32 %0, %1" : "=v"(wq.z) : "s"(wq.z));
             }
             // ---- rows: lane j < HR evaluates row j and the texel row of the row above it -----------------
-            unsigned covmask, chgmask, jmpmask;
+            mask_t covmask, chgmask, jmpmask;
             int r512;                                   // byte offset of this lane's texel row in PT
             {
                 const float d = pyc_own - pcy;
@@ -464,20 +466,20 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
                 if (rowlane) rt[myrow] = make_float2(fr, cv - fr);
                 asm volatile("" ::: "memory");
                 const bool covered = rowlane && cv != 0.0f;
-                covmask = (unsigned)__ballot(covered);
-                chgmask = (unsigned)__ballot(covered && myrow > 0 && r != rprev);
+                covmask = (mask_t)__ballot(covered);
+                chgmask = (mask_t)__ballot(covered && myrow > 0 && r != rprev);
                 // texel rows advance by at most one per pixel row when P >= 64; rounding at P ~ 64 may still skip one
-                jmpmask = (unsigned)__ballot(covered && myrow > 0 && r != rprev && r != rprev + 1);
+                jmpmask = (mask_t)__ballot(covered && myrow > 0 && r != rprev && r != rprev + 1);
             }
-            if (covmask == 0u) continue;
+            if (covmask == 0) continue;
             {   // the first covered row loads both texel rows
-                const unsigned first = covmask & (0u - covmask);
+                const mask_t first = covmask & ((mask_t)0 - covmask);
                 chgmask |= first; jmpmask |= first;
             }
             // row factors of group k for the DPP broadcast: lane l takes rows 4k + (l & 3)
             // HR = 16: the four groups' factors sit in registers; HR = 32: two registers pairs in turn (group K + 1 loads while
             // group K is walked), 12 VGPRs fewer -- what lets the 64 x 32 strips run at 6 waves per SIMD
-            constexpr bool JIT = (HR == 32);
+            constexpr bool JIT = (HR >= 32);
             constexpr int NRF = JIT ? 2 : NG;
             float2 rowf[NRF];
             if constexpr (JIT) rowf[0] = rt_quad[0];
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 #define TSP_H2_ROW(K, T)                                                                                       \
             {                                                                                                  \
                 constexpr int ty_ = 4 * (K) + (T);                                                             \
-                if ((chgmask >> ty_) & 1u) row_change(ty_, ((jmpmask >> ty_) & 1u) != 0u);                       \
+                if ((chgmask >> ty_) & 1) row_change(ty_, ((jmpmask >> ty_) & 1) != 0);                       \
                 _Pragma("unroll") for (int w = 0; w < W; ++w) {                                                \
                     float *ac = acc[ty_ * W + w];                                                              \
                     if (NACC == 1) {                                                                           \
@@ -560,21 +562,23 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 #define TSP_H2_GROUP(K)                                                                                        \
             if constexpr ((K) < NG) {                                                                          \
                 if constexpr (JIT && (K) + 1 < NG) rowf[((K) + 1) & 1] = rt_quad[4 * ((K) + 1)];               \
-                if (((covmask >> (4 * (K))) & 15u) != 0u) {                                                    \
+                if (((covmask >> (4 * (K))) & 15) != 0) {                                                    \
                     if constexpr (JIT) asm volatile("" : "+v"(rowf[(K) & 1].x), "+v"(rowf[(K) & 1].y));        \
                     TSP_H2_ROW(K, 0) TSP_H2_ROW(K, 1) TSP_H2_ROW(K, 2) TSP_H2_ROW(K, 3)                          \
                 }                                                                                              \
             }
             TSP_H2_GROUP(0) TSP_H2_GROUP(1) TSP_H2_GROUP(2) TSP_H2_GROUP(3)
             TSP_H2_GROUP(4) TSP_H2_GROUP(5) TSP_H2_GROUP(6) TSP_H2_GROUP(7)
+            TSP_H2_GROUP(8) TSP_H2_GROUP(9) TSP_H2_GROUP(10) TSP_H2_GROUP(11)
+            TSP_H2_GROUP(12) TSP_H2_GROUP(13) TSP_H2_GROUP(14) TSP_H2_GROUP(15)
 #undef TSP_H2_GROUP
 #undef TSP_H2_ROW
-            if (CNT) n_frag += (unsigned long long)(ncov_x * __popc(covmask));
+            if (CNT) n_frag += (unsigned long long)(ncov_x * __popcll((unsigned long long)covmask));
 #ifdef TSP_H2_DEBUG      // analysis build: (footprint, strip) pairs, covered rows and texel-row changes instead of the S / M / H3 fragment counts
             if (CNT && lane == 0) {
                 atomicAdd(&a.cnt->n_frag_class[0], 1ull);
-                atomicAdd(&a.cnt->n_frag_class[1], (unsigned long long)__popc(covmask));
-                atomicAdd(&a.cnt->n_frag_class[3], (unsigned long long)__popc(chgmask));
+                atomicAdd(&a.cnt->n_frag_class[1], (unsigned long long)__popcll((unsigned long long)covmask));
+                atomicAdd(&a.cnt->n_frag_class[3], (unsigned long long)__popcll((unsigned long long)chgmask));
             }
 #endif
         }
@@ -1330,6 +1334,8 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
         else if (ctx->mega_variant == 2 || (ctx->mega_variant == 0 && n_mega >= 40000)) rc = launch_mega64<MODE, 4>(ctx, ta, n_mega);
         else if (ctx->mega_variant == 3) rc = launch_mega64<MODE, 3>(ctx, ta, n_mega);
         else if (ctx->mega_variant == 4) rc = launch_mega<MODE, 1, 2, 5>(ctx, ta, n_mega);
+        // (round 4: the records >= 256 px through kernel H2 on LARGER strips -- fewer (footprint, strip) pairs to set up -- lose to
+        // their lower occupancy: 64x32 at 6 waves/SIMD 8.6 ms, 128x32 at 4: 10.4, 64x64 at 4: 12.9 for the same records)
         else rc = launch_mega<MODE, 1, 2, 4>(ctx, ta, n_mega);   // 4 column blocks per strip and 5-6 waves/SIMD measured no faster
         if (rc) return rc;
     }
