@@ -1275,7 +1275,8 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
         // rgb: kernel H2 with three accumulator sets since round 4 (116 VGPRs once its flush left the hot loop: 13.0 ms against
         // kernel H's 14.8 ms for the 64-128 px band of config 4); huge_variant 0 keeps kernel H for A/B
         if (MODE == TSP_MODE_RGB && ctx->huge_variant != 0) {
-            rc = launch_huge2<MODE, 3, 1, 16, 4>(ctx, ta, n_huge);
+            if (ctx->huge_variant == 4) rc = launch_huge2<MODE, 3, 1, 16, 4>(ctx, ta, n_huge);
+            else rc = launch_huge2<MODE, 3, 1, 16, 5>(ctx, ta, n_huge);      // 96 VGPRs at 5 waves/SIMD: 11.5 against 12.5 ms at 4 (config 4)
         } else if (ctx->huge_variant == 0 || MODE == TSP_MODE_RGB) {
             const size_t smem_h = (size_t)(64 * 64 + 512) * sizeof(float4);
             if (MODE == TSP_MODE_RGB) rc = launch_huge<MODE, 3, 4>(ctx, ta, smem_h, n_huge);
@@ -1287,17 +1288,19 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
         } else {                                // kernel H2 (row-uniform gather): 64 px <= P < p_mega
             if (second_channel) {
                 if (ctx->huge_variant == 4) rc = launch_huge2<MODE, 2, 1, 16, 5>(ctx, ta, n_huge);
-                else rc = launch_huge2<MODE, 2, 1, 16, 4>(ctx, ta, n_huge);      // 5-6 waves/SIMD spill: 21 / 31 vs 16 ms
+                else if (ctx->huge_variant == 5) rc = launch_huge2<MODE, 2, 1, 16, 6>(ctx, ta, n_huge);
+                else rc = launch_huge2<MODE, 2, 1, 16, 4>(ctx, ta, n_huge);
             }
-            else if (ctx->huge_variant == 2) rc = launch_huge2<MODE, 1, 1, 32, 4>(ctx, ta, n_huge);
+            else if (ctx->huge_variant == 2) rc = launch_huge2<MODE, 1, 1, 32, 6>(ctx, ta, n_huge);
             else if (ctx->huge_variant == 4) rc = launch_huge2<MODE, 1, 1, 16, 7>(ctx, ta, n_huge);
             else if (ctx->huge_variant == 5) rc = launch_huge2<MODE, 1, 1, 16, 8>(ctx, ta, n_huge);
-            else if (ctx->huge_variant == 6) rc = launch_huge2<MODE, 1, 1, 16, 6>(ctx, ta, n_huge);
-            // Round 4, once the flush had left the hot loop (no scratch, 64-80 VGPRs): 64x32 strips at 6 waves/SIMD with the row
-            // factors fetched group by group -- half as many (footprint, strip) pairs to set up: 8.64 ms (1.25e8 particles) /
-            // 24.4 ms (1e9) against 9.0 / 27.4 for 64x16 strips at 8 waves/SIMD, 9.3 at 6, 9.5 at 7; 64x32 at 4: 9.4
-            // (with fewer records the shorter strips' finer work units win: 3.4e5 records 2.57 against 2.79 ms, 1.4e5: 1.27 against 1.73)
-            else if (ctx->huge_variant == 7 || (ctx->huge_variant == 1 && n_huge >= 700000)) rc = launch_huge2<MODE, 1, 1, 32, 6>(ctx, ta, n_huge);
+            else if (ctx->huge_variant == 6) rc = launch_huge2<MODE, 1, 1, 32, 7>(ctx, ta, n_huge);
+            // Round 4, once the flush had left the hot loop: 64x32 strips with the row factors fetched group by group -- half as
+            // many (footprint, strip) pairs to set up -- at 8 waves/SIMD (64 VGPRs; three reloads per 64-record batch): this kernel
+            // is latency-bound per wave, occupancy is what pays.  1.25e8 particles, records 64-768 px: 10.20 / 9.86 / 9.59 ms at
+            // 6 / 7 / 8 waves (1e9: 28.7 / 26.9 / 26.9); 64x16 strips at 8: 10.7.  With fewer records the shorter strips' finer work
+            // units win (3.4e5 records: 3.05 against 3.49 ms)
+            else if (ctx->huge_variant == 7 || (ctx->huge_variant == 1 && n_huge >= 700000)) rc = launch_huge2<MODE, 1, 1, 32, 8>(ctx, ta, n_huge);
             else rc = launch_huge2<MODE, 1, 1, 16, 8>(ctx, ta, n_huge);
         }
         if (rc) return rc;
