@@ -534,13 +534,13 @@ def cpu_baseline(args, n_total, M, sf, R):
         oracle_c.splat(d["x"], d["y"], d["z"], d["h"], d["mass"], None, None, mode=0, M=M, sf=float(sf), R=R, mips=mips)
         return time.perf_counter() - t
 
-    # grow the sample until the oracle needs >= ~cpu_seconds/2 of wall time (bounded: <= 5e7 particles)
+    # grow the sample until the oracle needs >= ~cpu_seconds/2 of wall time (bounded: <= 1e8 particles)
     n_s = 200000
     d = sample(n_s)
     run(d)                                   # warm-up
     secs = run(d)
-    while secs < 0.5 * args.cpu_seconds and n_s < min(5e7, n_total):
-        n_s = int(min(n_s * max(2.0, 0.8 * args.cpu_seconds / max(secs, 1e-3)), 5e7, n_total))
+    while secs < 0.5 * args.cpu_seconds and n_s < min(1e8, n_total):
+        n_s = int(min(n_s * max(2.0, 0.8 * args.cpu_seconds / max(secs, 1e-3)), 1e8, n_total))
         d = sample(n_s)
         secs = run(d)
     out = {"value": n_s / secs, "unit": "particles/s", "cores": cores, "kind": "port",
