@@ -369,9 +369,7 @@ def main():
                                            "of every v_mfma_f32_32x32x2_f32 (2 x 32 x 32 x 2 flop each)"}
     if world > 1 and not weak and not args.headline_only:
         # the same snapshot whole on ONE GPU (rank 0's, the others wait at the barrier): what N = 1 prints as `value`
-        try:
-            ctx.close()
-            ctx = None
+        try:       # (a second context next to this rank's shard: the communicator stays up until every rank is done)
             one = whole_snapshot_line(_native, mips, R, channels, local_rank, n_total, args, mode, lut, vmin, vmax)
             result["one_gpu_same_snapshot"] = one
             result["speedup_vs_1gpu_same_snapshot"] = one["ms_per_step"] / ms_per_step
