@@ -472,10 +472,9 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
                 jmpmask = (mask_t)__ballot(covered && myrow > 0 && r != rprev && r != rprev + 1);
             }
             if (covmask == 0) continue;
-            {   // the first covered row loads both texel rows
-                const mask_t first = covmask & ((mask_t)0 - covmask);
-                chgmask |= first; jmpmask |= first;
-            }
+            // the first covered row's texel rows are loaded before the row walk (below): it is never a "change"
+            const mask_t first = covmask & ((mask_t)0 - covmask);
+            chgmask &= ~first; jmpmask &= ~first;
             // row factors of group k for the DPP broadcast: lane l takes rows 4k + (l & 3)
             // HR = 16: the four groups' factors sit in registers; HR = 32: two registers pairs in turn (group K + 1 loads while
             // group K is walked), 12 VGPRs fewer -- what lets the 64 x 32 strips run at 6 waves per SIMD
@@ -507,26 +506,30 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             }
             float top[W], bot[W];
             float2 nxt[W];                              // prefetched pair of texel row r + 2
-            int r_off = 0;                              // byte offset of the current texel row (wave-uniform)
-#pragma unroll
-            for (int w = 0; w < W; ++w) { top[w] = bot[w] = 0.0f; nxt[w] = make_float2(0.f, 0.f); }
             auto pair_at = [&](int w, int byteoff) -> float2 {
                 const float *t = reinterpret_cast<const float *>(PTb + byteoff + caddr[w]);
                 return make_float2(t[0], t[1]);
             };
             auto lerp = [&](int w, float2 t) -> float { return __builtin_fmaf(t.y, fxs[w], t.x * gxs[w]); };
-            auto row_change = [&](int ty, bool jump) {      // `jump` is wave-uniform
-                if (jump) {
-                    r_off = __builtin_amdgcn_readlane(r512, ty);
+            // texel rows of the first covered pixel row (wave-uniform byte offset of its texel row in PT), the pair after them in flight
+            int r_off = __builtin_amdgcn_readlane(r512, (HR == 64 ? __ffsll((long long)covmask) : __ffs((int)covmask)) - 1);
 #pragma unroll
-                    for (int w = 0; w < W; ++w) { top[w] = lerp(w, pair_at(w, r_off)); bot[w] = lerp(w, pair_at(w, r_off + PT_STRIDE * 4)); }
-                } else {
-                    r_off += PT_STRIDE * 4;
+            for (int w = 0; w < W; ++w) {
+                top[w] = lerp(w, pair_at(w, r_off)); bot[w] = lerp(w, pair_at(w, r_off + PT_STRIDE * 4));
+                nxt[w] = pair_at(w, r_off + 2 * PT_STRIDE * 4);
+            }
+            // ONE way to advance a texel row -- top = bot, bot = the x-interpolated prefetched pair, the next pair loads -- so that the
+            // rolling registers never meet a second definition at a control-flow merge (with a separate reload-from-scratch path for
+            // the first row and for skips the compiler copied the pair aside on every change: three v_mov).  Where float32 rounding
+            // at P ~ 64 makes the texel row skip one, the step runs twice.
+            auto row_step = [&]() {
+                r_off += PT_STRIDE * 4;
 #pragma unroll
-                    for (int w = 0; w < W; ++w) { top[w] = bot[w]; bot[w] = lerp(w, nxt[w]); }
-                }
-#pragma unroll
-                for (int w = 0; w < W; ++w) nxt[w] = pair_at(w, r_off + 2 * PT_STRIDE * 4);
+                for (int w = 0; w < W; ++w) { top[w] = bot[w]; bot[w] = lerp(w, nxt[w]); nxt[w] = pair_at(w, r_off + 2 * PT_STRIDE * 4); }
+            };
+            auto row_change = [&](int /*ty*/, bool skip) {      // `skip` is wave-uniform
+                if (skip) row_step();                           // (rare; first, so that the common step below ends at the join)
+                row_step();
             };
             // DPP hazard (gfx9: a VGPR written by a VALU instruction may not be read as a DPP operand in the next two issue
             // slots).  The DPP operands below are the row factors: they come from LDS (no VALU write) long before their use,
