@@ -525,7 +525,13 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             auto row_step = [&]() {
                 r_off += PT_STRIDE * 4;
 #pragma unroll
-                for (int w = 0; w < W; ++w) { top[w] = bot[w]; bot[w] = lerp(w, nxt[w]); nxt[w] = pair_at(w, r_off + 2 * PT_STRIDE * 4); }
+                for (int w = 0; w < W; ++w) {
+                    // top = bot; bot = nxt.x * gx + nxt.y * fx -- in place (left to the compiler the new row lands in a third register
+                    // and is moved: one more v_mov per texel-row change)
+                    asm volatile("v_mov_b32 %0, %1\n\tv_mul_f32 %1, %2, %4\n\tv_fmac_f32 %1, %3, %5"
+                                 : "=&v"(top[w]), "+v"(bot[w]) : "v"(nxt[w].x), "v"(nxt[w].y), "v"(gxs[w]), "v"(fxs[w]));
+                    nxt[w] = pair_at(w, r_off + 2 * PT_STRIDE * 4);
+                }
             };
             auto row_change = [&](int /*ty*/, bool skip) {      // `skip` is wave-uniform
                 if (skip) row_step();                           // (rare; first, so that the common step below ends at the join)
