@@ -363,7 +363,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
         const int j = min(i / PT_STRIDE, 63), x = min(i % PT_STRIDE, 63);
         PT[i] = a.mips[j * 64 + x];
     }
-    float2 *rt = rt_all + wv * HR;
+    float2 *rt = rt_all + wv * 64;
     const float2 *rt_quad = rt + (lane & 3);               // this lane's slot in every row group
     const int sx = tx0 + 64 * W * (wv & 1), sy = ty0 + HR * (wv >> 1);
     const float sx0 = (float)sx, sx1 = (float)(sx + 64 * W), sy0 = (float)sy, sy1 = (float)(sy + HR);
@@ -371,7 +371,6 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 #pragma unroll
     for (int w = 0; w < W; ++w) pxc[w] = (sx + 64 * w + lane < R) ? (float)(sx + 64 * w + lane) + 0.5f : __builtin_inff();
     const int myrow = lane & (HR - 1);
-    const bool rowlane = lane < HR;
     const float pyc_own = (sy + myrow < R) ? (float)(sy + myrow) + 0.5f : __builtin_inff();
 
     // float32 accumulators hold at most FOLD_EVERY footprints (rounding error ~ sqrt(n) * 2^-24 relative: < 2e-6 at
@@ -463,13 +462,16 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
                 const int rprev = __builtin_amdgcn_mov_dpp(r, 0x138, 0xf, 0xf, false);
                 r512 = r * (PT_STRIDE * 4);
                 asm volatile("" ::: "memory");          // (in-order LDS: the previous footprint's table reads are done)
-                if (rowlane) rt[myrow] = make_float2(fr, cv - fr);
+                rt[lane] = make_float2(fr, cv - fr);      // (every lane writes: the table has 64 slots per wave, the rows sit in the first HR)
                 asm volatile("" ::: "memory");
-                const bool covered = rowlane && cv != 0.0f;
-                covmask = (mask_t)__ballot(covered);
-                chgmask = (mask_t)__ballot(covered && myrow > 0 && r != rprev);
+                // the row masks straight from vector compares (as __ballot(bool expression) each costs a v_cndmask + v_cmp round trip);
+                // the lanes that hold rows, and row 0 of the strip, are constants
+                constexpr unsigned long long ROWS = (HR == 64) ? ~0ull : ((1ull << (HR & 63)) - 1ull);
+                const unsigned long long cov64 = __builtin_amdgcn_fcmpf(__builtin_fabsf(d), half, 4 /* FCMP_OLT */) & ROWS;
+                const unsigned long long chg64 = __builtin_amdgcn_uicmp((unsigned)r, (unsigned)rprev, 33 /* ICMP_NE */) & cov64 & ~1ull;
                 // texel rows advance by at most one per pixel row when P >= 64; rounding at P ~ 64 may still skip one
-                jmpmask = (mask_t)__ballot(covered && myrow > 0 && r != rprev && r != rprev + 1);
+                const unsigned long long jmp64 = __builtin_amdgcn_uicmp((unsigned)r, (unsigned)(rprev + 1), 33 /* ICMP_NE */) & chg64;
+                covmask = (mask_t)cov64; chgmask = (mask_t)chg64; jmpmask = (mask_t)jmp64;
             }
             if (covmask == 0) continue;
             // the first covered row's texel rows are loaded before the row walk (below): it is never a "change"
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 template <int MODE, int NACC, int W, int HR, int OCC>
 static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
     TSP_REQUIRE(ta.n_records < (1ll << 31), TSP_EINVAL, "%lld deferred footprints in one render block (the tile-gather kernels index them with 32 bits)", ta.n_records);
-    const size_t smem = (size_t)((PT_ROWS * PT_STRIDE + 3) & ~3) * sizeof(float) + (H2T / 64) * HR * sizeof(float2);
+    const size_t smem = (size_t)((PT_ROWS * PT_STRIDE + 3) & ~3) * sizeof(float) + (H2T / 64) * 64 * sizeof(float2);
     const int tw = 2 * 64 * W, th = 2 * HR;
     const int htiles_x = (ctx->R + tw - 1) / tw, htiles_y = (ctx->R + th - 1) / th;
     const int htiles = htiles_x * htiles_y;
