@@ -478,6 +478,8 @@ def test_gather_kernel_class_boundaries(native, mips, mode, R):
     ctx = native.Context(R, 4 if mode == "rgb" else 2)
     ctx.set_kernel_mips(mips)
     ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, None if mode == "rgb" else m)
+    if mode == "rgb":
+        ctx.set_option("p_mega_rgb_px", 128)   # rgb draws everything >= 64 px with kernel H2 by default (round 4): H3 from 128 px here
     for count in (1, 0):                       # with fragment statistics (no disc culling), then with the exact culling
         ctx.set_option("count_fragments", count)
         if mode == "rgb":
@@ -504,7 +506,7 @@ def test_gather_kernel_class_boundaries(native, mips, mode, R):
         assert 0 < st["n_mega"] <= wide             # (some of them are off-screen or outside the z-slab)
         assert st["n_mega"] > wide // 3
     # the kernel variants that large record counts (or options) select, same scene, exact culling on
-    extra = {"rgb": [("rgb_mega_variant", 1), ("rgb_mega_variant", 3), ("rgb_mega_variant", 4), ("huge_variant", 0)],
+    extra = {"rgb": [("rgb_mega_variant", 1), ("rgb_mega_variant", 3), ("rgb_mega_variant", 4), ("huge_variant", 0), ("p_mega_rgb_px", 0)],
              "weighted": [("mega_variant", 4), ("mega_variant", 3), ("mega_variant", 5), ("huge_variant", 4)],
              "depth": [("mega_variant", 4), ("mega_variant", 5)]}[mode]
     for name, value in extra:
@@ -520,7 +522,7 @@ def test_gather_kernel_class_boundaries(native, mips, mode, R):
         else:
             ctx.render(M, sf, mode=native.MODE_WEIGHTED)
             check_2ch(ctx.read_image(), want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
-        ctx.set_option(name, {"rgb_mega_variant": 2, "mega_variant": 0, "huge_variant": 1}[name])
+        ctx.set_option(name, {"rgb_mega_variant": 2, "mega_variant": 0, "huge_variant": 1, "p_mega_rgb_px": 128}[name])
     ctx.close()
 
 

@@ -362,6 +362,7 @@ def test_record_list_overflow_replay_with_mega_records(native, mips, label, h_va
         c2.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
         c2.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
         c2.set_option("p_mega_px", 512)          # (the default moved to 768 px in round 4; 614-px footprints must stay mega records here)
+        c2.set_option("p_mega_rgb_px", 128)      # (rgb: no H3 by default since round 4)
         c2.render(M, sf, mode=mode)              # first frame: overflow -> grow -> replay
         st = c2.stats()
         a = c2.read_image().astype(np.float64)

@@ -119,7 +119,7 @@ struct tsp_context {
     float p_small = 16.0f;             // footprints narrower than this many pixels are splatted by kernel S (mips 3 and 2; <= 16: its texel columns are packed 16 x 4 bits)
     float p_mega = 768.0f;            // density renders: footprints at least this wide go to kernel H3 (matrix cores); 0 = all to H2.  Round 4: the de-spilled H2 on 64x32 strips moved the break-even up from 512 px (1e9: 79.2 -> 77.2 ms; 1024 / 2048 / no H3 at all: 77.3 / 78.4 / 78.1)
     float p_mega2 = 384.0f;           // the same for two-channel renders (weighted, depth): their H2 pays 5 instead of 2 FMAs per pixel row (round 4: 384 against 256 px: 33.4 / 33.9 ms at 1.25e8 weighted, 9.22 / 9.30 at 1e7)
-    float p_mega_rgb = 128.0f;        // ... and for rgb (kernel H below, kernel H3 with three accumulator sets above)
+    float p_mega_rgb = 0.0f;          // ... and for rgb: 0 = no H3 at all since round 4 -- kernel H2 with three accumulator sets draws every footprint >= 64 px (config 4: 77.9 ms against 85.0 with H3 from 128 px, 82.7 / 80.3 from 384 / 768 px; 5e6 particles at 1024^2: 14.9 against 18.3 ms)
     float integrated_px = 0.0f;       // option: density footprints at least this wide (>= 128) go through kernel I (second differences + prefix sums, tsp_integrated.hip); 0 = off
     float int_peak = 0.0f;            // kernel I: largest level-0 texel
     unsigned long long int_edge[2] = {0, 0};   // kernel I: rows of S0 with a non-zero edge jump (bit q of 66)
