@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--no-reorder", action="store_true")
     ap.add_argument("--integrated-px", type=int, default=0,
                     help="option integrated_px of the library (kernel I for footprints at least this wide); 0 = the default path")
+    ap.add_argument("--p-mega-px", type=int, default=0,
+                    help="option p_mega_px / p_mega2_px of the library: footprints at least this wide go to the matrix-core kernel "
+                         "H3 (0 = the default since the end of round 4: kernel H2 draws every footprint >= 64 px)")
     ap.add_argument("--shared-device-dry-run", action="store_true",
                     help="harness test on a 1-GPU box: every rank uses device 0 and the image reduce is skipped (RCCL refuses two "
                          "ranks on one device), so the launcher logic of an N > 1 run -- rendezvous, shards, barriers, the "
@@ -129,6 +132,8 @@ def make_context(_native, mips, R, channels, device, n_total, first, count, args
                            with_quantity=mode_name == "weighted", with_rgb=mode_name == "rgb")
     if not args.no_reorder:
         ctx.reorder_spatial(num_strata(count), 1337)       # load-time ordering, as the product path does
+    if args.p_mega_px:
+        ctx.set_option("p_mega_px", args.p_mega_px); ctx.set_option("p_mega2_px", args.p_mega_px)
     return ctx
 
 
@@ -297,6 +302,7 @@ def main():
                      + (f"index-range sharded x{world} ({n_per:.4g}/GPU)" if world > 1 else "whole snapshot resident on one GPU")
                      + (f", h capped at {args.h_cap_px:g} px" if args.h_cap_px > 0 else "")
                      + (f", option integrated_px = {args.integrated_px}" if args.integrated_px else "")
+                     + (f", option p_mega_px = {args.p_mega_px}" if args.p_mega_px else "")
                      + ", splat + " + ("RCCL image reduce + " if world > 1 else "") + "colormap")
     measured_peak = ctx.measure_read_bandwidth(4 << 30, 5)
     # HBM bytes of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE doubled as
@@ -324,7 +330,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload_name, "total_particles": n_total,
                    "particles_per_gpu": n_per, "resolution": R, "sharding": f"index-range x{world}",
-                   "pipeline": "generic" if args.generic else "four-class (stream / mid scatter / row-uniform gather / MFMA)",
+                   "pipeline": "generic" if args.generic else ("four-class (stream / mid scatter / row-uniform gather / MFMA)" if args.p_mega_px
+                                                               else "three-class (stream / mid scatter / row-uniform gather)"),
                    "fragments_per_particle": frags / n_total, "frames_per_s": 1e3 / ms_per_step},
         "ms_per_step_median": ms_median, "value_at_median": n_total / (ms_median * 1e-3),
         "fragments_per_s": frags / (ms_per_step * 1e-3),
@@ -376,7 +383,8 @@ def main():
         except _native.BackendError as e:
             result["one_gpu_same_snapshot"] = {"error": str(e)[:200]}
             result["speedup_vs_1gpu_same_snapshot"] = None
-    extras = world == 1 and not args.generic and not args.headline_only and args.h_cap_px <= 0 and not args.integrated_px
+    extras = (world == 1 and not args.generic and not args.headline_only and args.h_cap_px <= 0 and not args.integrated_px
+              and not args.p_mega_px)
     if extras and args.mode == "density":
         if ctx is not None:
             ctx.close()
@@ -387,6 +395,7 @@ def main():
         ctx = make_context(_native, mips, R, 2, local_rank, n_sh, 0, n_sh, args)
         result["shard_1p25e8"] = config_line(ctx, n_sh, "density", R, args, "a 1.25e8-particle snapshot (the headline of "
                                              "rounds 1-3; h-law of N = 1.25e8)", regenerate=False)
+        result["matrix_core_option"] = matrix_core_line(ctx, M, sf, mode, n_sh)
         result["integrated_option"] = integrated_line(ctx, M, sf, mode, n_sh)
         result["bandwidth_regime"] = hcapped_line(args, ctx, n_sh, n_sh, 0, M, sf, mode, measured_peak)
         # the other single-GPU configurations of BASELINE.json, driver-timed beside the headline (never `value`)
@@ -431,6 +440,35 @@ def whole_snapshot_line(_native, mips, R, channels, device, n_total, args, mode,
     return {"workload": f"the same {n_total:.4g}-particle snapshot whole on one GPU", "ms_per_step": ms,
             "value": n_total / (ms * 1e-3), "unit": "particles/s", "frames": frames,
             "kernel_ms": {k: st["ms_" + k] for k in KERNELS}}
+
+
+def matrix_core_line(ctx, M, sf, mode, n_per, px=768, frames=10):
+    """The frame with kernel H3 (v_mfma_f32_32x32x2_f32) drawing the footprints >= px -- the default of rounds 2-4 -- beside the
+    default path, whose kernel H2 draws them: why the matrix cores are an option now."""
+    def run():
+        ms, h2, h3 = [], [], []
+        for i in range(frames + 1):
+            t = ctx.render(M, sf, clear=True, mode=mode)
+            if i:
+                st = ctx.stats(); ms.append(t); h2.append(st["ms_huge"]); h3.append(st["ms_mega"])
+        return float(np.median(ms)), float(np.median(h2)), float(np.median(h3))
+    ms0, h20, _ = run()
+    _, by0 = count_fragments(ctx, M, sf, mode)
+    ctx.set_option("p_mega_px", px)
+    ms1, h21, h31 = run()
+    _, by1 = count_fragments(ctx, M, sf, mode)
+    n_mega = int(ctx.stats()["n_mega"])
+    ctx.set_option("p_mega_px", 0)
+    useful = float(by1["mega"]) * FMAS_PER_FRAGMENT["mega"] * 2.0
+    return {"workload": f"the 1.25e8-particle snapshot with the option p_mega_px = {px} (footprints >= {px} px through kernel H3)",
+            "ms_per_step": ms1, "ms_per_step_default_path": ms0, "value": n_per / (ms1 * 1e-3), "unit": "particles/s",
+            "kernel_H2_ms": h21, "kernel_H3_ms": h31, "kernel_H2_ms_default_path": h20, "records_through_kernel_H3": n_mega,
+            "fragments_through_kernel_H3": int(by1["mega"]),
+            "kernel_H2_ms_for_the_same_fragments": h20 - h21,
+            "roofline_mega": {"bound": "mfma", "achieved": useful / (h31 * 1e-3) / 1e12 if h31 > 0 else 0.0, "peak": MFMA_F32_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": useful / (h31 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if h31 > 0 else 0.0,
+                              "note": "useful flop (fragments x 2 FMAs x 2); f32 MFMA and packed-f32 VALU share one peak on gfx950, and "
+                                      "the GEMM form issues 1.9x the useful flop (profiles/round4d: useful_frac 0.52, issued_frac 0.50)"}}
 
 
 def integrated_line(ctx, M, sf, mode, n_per, px=256, frames=10):

@@ -39,6 +39,12 @@ def check_2ch(got, want, abs_terms, rtol=1e-5):
     assert (d1 <= rtol * abs_terms + 1e-30).all(), "weighted channel beyond atol scaled by sum|terms|"
 
 
+def matrix_cores_on(ctx):
+    """Kernel H3 is an option since the end of round 4 (all three boundaries default to 0 = kernel H2 draws every footprint
+    >= 64 px): the boundaries of rounds 1-3 for the tests that cover it."""
+    ctx.set_option("p_mega_px", 512); ctx.set_option("p_mega2_px", 256); ctx.set_option("p_mega_rgb_px", 128)
+
+
 CAMERAS = [
     ("identity", np.eye(3), np.zeros(3), 200.0),
     ("zoom_rot", None, np.array([1.5, -2.0, 0.25]), 35.0),
@@ -53,7 +59,7 @@ def _rot(a, b):
     return rx @ ry
 
 
-@pytest.mark.parametrize("pipe", ["generic", "default"])
+@pytest.mark.parametrize("pipe", ["generic", "default", "matrix-cores"])
 @pytest.mark.parametrize("cam", CAMERAS, ids=[c[0] for c in CAMERAS])
 @pytest.mark.parametrize("R", [200, 1024])
 def test_weighted_matches_oracle(native, mips, cam, R, pipe):
@@ -67,6 +73,8 @@ def test_weighted_matches_oracle(native, mips, cam, R, pipe):
     ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
     ctx.upload_quantity(q)
     flags = native.PIPE_GENERIC if pipe == "generic" else native.PIPE_DEFAULT
+    if pipe == "matrix-cores":
+        matrix_cores_on(ctx)
     ctx.render(M, sf, mode=native.MODE_WEIGHTED, flags=flags)
     got = ctx.read_image()
     want, _ = oracle_render(pos, h, m, q, None, 0, M, sf, R, mips)
@@ -80,7 +88,7 @@ def test_weighted_matches_oracle(native, mips, cam, R, pipe):
     ctx.close()
 
 
-@pytest.mark.parametrize("pipe", ["generic", "default"])
+@pytest.mark.parametrize("pipe", ["generic", "default", "matrix-cores"])
 def test_rgb_and_depth_match_oracle(native, mips, pipe):
     from oracle import oracle_np
     R = 256
@@ -91,6 +99,8 @@ def test_rgb_and_depth_match_oracle(native, mips, pipe):
     ctx.set_kernel_mips(mips)
     ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, None)
     ctx.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
+    if pipe == "matrix-cores":
+        matrix_cores_on(ctx)
     ctx.render(M, sf, mode=native.MODE_RGB, flags=flags)
     got = ctx.read_image()
     want, _ = oracle_render(pos, h, rgb[:, 0].copy(), rgb[:, 1].copy(), rgb[:, 2].copy(), 2, M, sf, R, mips)
@@ -100,6 +110,8 @@ def test_rgb_and_depth_match_oracle(native, mips, pipe):
     ctx = native.Context(R, 2)
     ctx.set_kernel_mips(mips)
     ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+    if pipe == "matrix-cores":
+        matrix_cores_on(ctx)
     ctx.render(M, sf, mode=native.MODE_DEPTH, flags=flags)
     got = ctx.read_image()
     want, _ = oracle_render(pos, h, m, None, None, 1, M, sf, R, mips)
@@ -434,17 +446,20 @@ def test_randomised_views(native, mips, seed):
         want, nfrag = oracle_render(pos, h, m, q, None, 0, M, sf, R, mips)
         check_2ch(ctx.read_image(), want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
     assert ctx.stats()["n_fragments"] == nfrag
-    # and once more with the exact disc culling active (no fragment statistics)
+    # and once more with the exact disc culling active (no fragment statistics), then with the matrix-core kernel taking its share
     ctx.set_option("count_fragments", 0)
     md = {"weighted": native.MODE_WEIGHTED, "rgb": native.MODE_RGB, "depth": native.MODE_DEPTH}[mode]
-    ctx.render(M, sf, mode=md)
-    got = ctx.read_image()
-    if mode == "weighted":
-        check_2ch(got, want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
-    else:
-        assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=0)
-        if mode == "rgb":
-            assert np.array_equal(got[..., 3], want[..., 3])
+    for matrix_cores in (False, True):
+        if matrix_cores:
+            matrix_cores_on(ctx)
+        ctx.render(M, sf, mode=md)
+        got = ctx.read_image()
+        if mode == "weighted":
+            check_2ch(got, want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
+        else:
+            assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=0)
+            if mode == "rgb":
+                assert np.array_equal(got[..., 3], want[..., 3])
     ctx.close()
 
 
@@ -478,8 +493,8 @@ def test_gather_kernel_class_boundaries(native, mips, mode, R):
     ctx = native.Context(R, 4 if mode == "rgb" else 2)
     ctx.set_kernel_mips(mips)
     ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, None if mode == "rgb" else m)
-    if mode == "rgb":
-        ctx.set_option("p_mega_rgb_px", 128)   # rgb draws everything >= 64 px with kernel H2 by default (round 4): H3 from 128 px here
+    # kernel H2 draws everything >= 64 px by default (rgb: round 4; density, two-channel: end of round 4): H3 from 128 / 384 px here
+    ctx.set_option("p_mega_rgb_px", 128); ctx.set_option("p_mega2_px", 384)
     for count in (1, 0):                       # with fragment statistics (no disc culling), then with the exact culling
         ctx.set_option("count_fragments", count)
         if mode == "rgb":
@@ -507,8 +522,8 @@ def test_gather_kernel_class_boundaries(native, mips, mode, R):
         assert st["n_mega"] > wide // 3
     # the kernel variants that large record counts (or options) select, same scene, exact culling on
     extra = {"rgb": [("rgb_mega_variant", 1), ("rgb_mega_variant", 3), ("rgb_mega_variant", 4), ("huge_variant", 0), ("p_mega_rgb_px", 0)],
-             "weighted": [("mega_variant", 4), ("mega_variant", 3), ("mega_variant", 5), ("huge_variant", 4)],
-             "depth": [("mega_variant", 4), ("mega_variant", 5)]}[mode]
+             "weighted": [("mega_variant", 4), ("mega_variant", 3), ("mega_variant", 5), ("huge_variant", 4), ("p_mega2_px", 0)],
+             "depth": [("mega_variant", 4), ("mega_variant", 5), ("p_mega2_px", 0)]}[mode]
     for name, value in extra:
         ctx.set_option(name, value)
         if mode == "rgb":
@@ -522,7 +537,7 @@ def test_gather_kernel_class_boundaries(native, mips, mode, R):
         else:
             ctx.render(M, sf, mode=native.MODE_WEIGHTED)
             check_2ch(ctx.read_image(), want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
-        ctx.set_option(name, {"rgb_mega_variant": 2, "mega_variant": 0, "huge_variant": 1, "p_mega_rgb_px": 128}[name])
+        ctx.set_option(name, {"rgb_mega_variant": 2, "mega_variant": 0, "huge_variant": 1, "p_mega_rgb_px": 128, "p_mega2_px": 384}[name])
     ctx.close()
 
 
@@ -544,7 +559,7 @@ def test_gather_kernels_fold_their_accumulators(native, mips):
     ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
     ctx.set_option("huge_split", 1)
     ctx.set_option("mega_split", 1)
-    ctx.set_option("p_mega_px", 512)           # the class split this scene was laid out for (default since round 4: 768 px)
+    ctx.set_option("p_mega_px", 512)           # the class split this scene was laid out for (kernel H3 is an option since the end of round 4)
     ctx.render(M, sf)
     got = ctx.read_image()
     assert ctx.stats()["n_mega"] == n // 2 and ctx.stats()["n_huge"] == n

@@ -300,7 +300,7 @@ def test_config2_weighted_1e7_full_size(native, mips):
     ctx.set_option("count_fragments", 1)
     ctx.render(M, sf, mode=native.MODE_WEIGHTED)
     st = ctx.stats()
-    assert st["n_small"] + st["n_mid"] + st["n_huge"] + st["n_culled"] == n and st["n_mega"] > 0
+    assert st["n_small"] + st["n_mid"] + st["n_huge"] + st["n_culled"] == n and st["n_huge"] > 0 and st["n_mega"] == 0
     fa = st["n_fragments"]
     a = ctx.read_image().astype(np.float64)
     ctx.render(M, sf, mode=native.MODE_WEIGHTED, flags=native.PIPE_GENERIC)

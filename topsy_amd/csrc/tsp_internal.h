@@ -117,8 +117,13 @@ struct tsp_context {
     bool count_fragments = false;
     // pipeline tuning (tsp_set_option)
     float p_small = 16.0f;             // footprints narrower than this many pixels are splatted by kernel S (mips 3 and 2; <= 16: its texel columns are packed 16 x 4 bits)
-    float p_mega = 768.0f;            // density renders: footprints at least this wide go to kernel H3 (matrix cores); 0 = all to H2.  Round 4: the de-spilled H2 on 64x32 strips moved the break-even up from 512 px (1e9: 79.2 -> 77.2 ms; 1024 / 2048 / no H3 at all: 77.3 / 78.4 / 78.1)
-    float p_mega2 = 384.0f;           // the same for two-channel renders (weighted, depth): their H2 pays 5 instead of 2 FMAs per pixel row (round 4: 384 against 256 px: 33.4 / 33.9 ms at 1.25e8 weighted, 9.22 / 9.30 at 1e7)
+    float p_mega = 0.0f;              // density renders: footprints at least this wide go to kernel H3 (matrix cores); 0 = all to H2, the default since the
+                                      // end of round 4.  f32 MFMA and packed-f32 VALU have the SAME peak on gfx950 (256 flop/clk/CU); the GEMM form issues 2 K flop per
+                                      // pixel (K = texel rows under 32 pixel rows, padded to >= 2, typically 4) where H2 issues 4, so once H2 had lost its spills
+                                      // H3 only wins from ~1536 px up (measured: H3 off, 1e7 7.07 -> 6.2 ms, 1e8 19.6 -> 18.1, 1.25e8 21.4 -> 20.5, 1e9 68.1 -> 66.7;
+                                      // only a 10x zoom at 1e8 -- every record wider than the image -- is 4 % faster with it).  History: 512 px (round 3), 768 (round 4)
+    float p_mega2 = 0.0f;             // the same for two-channel renders (weighted, depth); 0 since the end of round 4 too (H3 off: 1e7 weighted 9.03 -> 8.68 ms,
+                                      // 1e8 28.7 -> 27.7, 5e8 71.5 -> 69.2; before: 256 px, then 384)
     float p_mega_rgb = 0.0f;          // ... and for rgb: 0 = no H3 at all since round 4 -- kernel H2 with three accumulator sets draws every footprint >= 64 px (config 4: 77.9 ms against 85.0 with H3 from 128 px, 82.7 / 80.3 from 384 / 768 px; 5e6 particles at 1024^2: 14.9 against 18.3 ms)
     float integrated_px = 0.0f;       // option: density footprints at least this wide (>= 128) go through kernel I (second differences + prefix sums, tsp_integrated.hip); 0 = off
     float int_peak = 0.0f;            // kernel I: largest level-0 texel
