@@ -65,7 +65,9 @@ const char *tsp_last_error(void);
  * version-101 library (check tsp_version() >= 101 and tsp_stats_size() == sizeof(tsp_stats) at start-up).  The same
  * release narrowed the option "p_small_milli" from <= 22627 to <= 16000 (kernel S packs at most 16 texel columns per
  * footprint; the default moved from 13.5 to 16 px): values 16001..22627 now return TSP_EINVAL.
- * 102: tsp_stats grew by 32 bytes (n_fragments_stream / _mid / _huge / _mega appended); same rule. */
+ * 102: tsp_stats grew by 32 bytes (n_fragments_stream / _mid / _huge / _mega appended); same rule.
+ * 103: tsp_stats grew by 8 bytes (n_chunk_culled appended); same rule.  Defaults changed without an ABI change: kernel H3
+ * (matrix cores) is an option ("p_mega_px" / "p_mega2_px" default to 0), chunk culling ("chunk_cull") is on. */
 int tsp_version(void);
 int tsp_stats_size(void);
 
@@ -227,6 +229,9 @@ typedef struct {
     /* n_fragments by the kernel that drew them (counted like n_fragments; 0 on the generic pipeline): kernel S, kernel M,
      * kernel H / H2, kernel H3 (or kernel I) -- what bench.py prices each kernel's fragment-rate roofline with */
     int64_t n_fragments_stream, n_fragments_mid, n_fragments_huge, n_fragments_mega;
+    /* of n_culled: particles of chunks (512 consecutive particles) whose bounding box lay outside the view -- never read
+     * (option "chunk_cull", on by default; needs >= 4096 chunks in the call, pays after tsp_reorder_spatial) */
+    int64_t n_chunk_culled;
 } tsp_stats;
 int tsp_get_stats(tsp_context *ctx, tsp_stats *out);
 /* Options by name.  "count_fragments" (0/1): fragment counting (adds atomics; off by default).  "integrated_px" (0 = off, the

@@ -16,7 +16,7 @@ MODE_WEIGHTED, MODE_DEPTH, MODE_RGB = 0, 1, 2
 PIPE_DEFAULT, PIPE_GENERIC = 0, 1
 SAMPLE_BILINEAR_MIP0, SAMPLE_BILINEAR_MIP = 0x10, 0x20      # diagnostic sampling rules (generic kernel)
 UNIQUE_ID_BYTES = 128
-ABI_VERSION = 102            # include/topsy_splat.h: tsp_version()
+ABI_VERSION = 103            # include/topsy_splat.h: tsp_version()
 
 
 class BackendUnavailable(RuntimeError):
@@ -33,7 +33,7 @@ class Stats(ctypes.Structure):
                 ("ms_stream", ctypes.c_double), ("ms_mid", ctypes.c_double), ("ms_huge", ctypes.c_double),
                 ("ms_total", ctypes.c_double), ("ms_mega", ctypes.c_double), ("n_mega", ctypes.c_int64),
                 ("n_fragments_stream", ctypes.c_int64), ("n_fragments_mid", ctypes.c_int64),
-                ("n_fragments_huge", ctypes.c_int64), ("n_fragments_mega", ctypes.c_int64)]
+                ("n_fragments_huge", ctypes.c_int64), ("n_fragments_mega", ctypes.c_int64), ("n_chunk_culled", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -85,6 +85,7 @@ static void free_particles(tsp_context *ctx) {
     if (p.perm) (void)hipFree(p.perm);
     p.perm = nullptr;
     p.n = 0;
+    ctx->ws.bounds_valid = false;
     ctx->strata_offsets.clear();
     ctx->cell_offsets.clear();
     ctx->cell_bits = 0;
@@ -97,7 +98,7 @@ using namespace tsp;
 extern "C" {
 
 const char *tsp_last_error(void) { return g_err; }
-int tsp_version(void) { return 102; }     // 101: tsp_stats gained ms_mega, n_mega (16 bytes); 102: the per-kernel fragment counts (32 bytes)
+int tsp_version(void) { return 103; }     // 101: tsp_stats gained ms_mega, n_mega (16 bytes); 102: the per-kernel fragment counts (32 bytes); 103: n_chunk_culled (8 bytes)
 int tsp_stats_size(void) { return (int)sizeof(tsp_stats); }
 
 int tsp_device_count(void) {
@@ -165,7 +166,7 @@ void tsp_destroy(tsp_context *ctx) {
     free_particles(ctx);
     void *ptrs[] = {ctx->image, ctx->image64, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->lut2d, ctx->scratch,
                     ctx->ws.mid_geom, ctx->ws.mid_w, ctx->ws.huge_geom, ctx->ws.huge_w, ctx->ws.seg_count, ctx->ws.seg_offset,
-                    ctx->ws.seg_bbox, ctx->ws.band_count, ctx->ws.band_list, ctx->ws.range_prefix, ctx->ws.count_diff, ctx->ws.count_band, ctx->ws.int_d2, ctx->ws.int_part, ctx->ws.int_wmax, ctx->int_tables, ctx->sort_keys, ctx->sort_keys_alt, ctx->sort_tmp};
+                    ctx->ws.seg_bbox, ctx->ws.band_count, ctx->ws.band_list, ctx->ws.block_bounds, ctx->ws.alive_list, ctx->ws.cull_info, ctx->ws.range_prefix, ctx->ws.count_diff, ctx->ws.count_band, ctx->ws.int_d2, ctx->ws.int_part, ctx->ws.int_wmax, ctx->int_tables, ctx->sort_keys, ctx->sort_keys_alt, ctx->sort_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &e : ctx->ev)
@@ -425,6 +426,7 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
     TSP_HIP(hipMemsetAsync(ctx->counters, 0, sizeof(Counters), ctx->stream));
     ctx->stats = tsp_stats{};
     ctx->stats.n_particles = total;
+    ctx->chunk_culled_particles = 0;
     int rc = TSP_OK;
     if (total > 0) {
         const int rule = (flags & TSP_SAMPLE_BILINEAR_MIP0) ? 1 : ((flags & TSP_SAMPLE_BILINEAR_MIP) ? 2 : 0);
@@ -468,7 +470,8 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
     ctx->stats.n_mid = (int64_t)hc.n_mid;
     ctx->stats.n_huge = (int64_t)(hc.n_huge + hc.n_mega);
     ctx->stats.n_mega = (int64_t)hc.n_mega;
-    ctx->stats.n_culled = (int64_t)hc.n_culled;
+    ctx->stats.n_culled = (int64_t)hc.n_culled + ctx->chunk_culled_particles;
+    ctx->stats.n_chunk_culled = ctx->chunk_culled_particles;
     ctx->stats.n_fragments = (int64_t)hc.n_fragments;
     ctx->stats.n_fragments_stream = (int64_t)hc.n_frag_class[0];
     ctx->stats.n_fragments_mid = (int64_t)hc.n_frag_class[1];
@@ -734,6 +737,10 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
     if (!strcmp(name, "huge_variant")) {
         TSP_REQUIRE(value >= 0 && value <= 7, TSP_EINVAL, "huge_variant out of range");
         ctx->huge_variant = (int)value;
+        return TSP_OK;
+    }
+    if (!strcmp(name, "chunk_cull")) {        // 1 (default): kernel S skips the chunks whose bounds lie outside the view
+        ctx->chunk_cull = value != 0;
         return TSP_OK;
     }
     if (!strcmp(name, "overlap_mid_huge")) {

@@ -85,6 +85,7 @@ int generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int64_t
                        int with_quantity, int with_rgb) {
     Particles &p = ctx->p;
     p.n = count;
+    ctx->ws.bounds_valid = false;
     if (count == 0) return TSP_OK;
     float **need[] = {&p.x, &p.y, &p.z, &p.h, &p.m};
     for (float **a : need) TSP_HIP(hipMalloc((void **)a, (size_t)count * sizeof(float)));
@@ -113,6 +114,53 @@ int generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int64_t
                        p.r, p.g, p.b);
     TSP_HIP(hipGetLastError());
     TSP_HIP(hipStreamSynchronize(ctx->stream));
+    return TSP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bounds of every block of BOUNDS_BLOCK consecutive particles (kernel S skips chunks that cannot reach the view)
+// ------------------------------------------------------------------------------------------------
+// One wave per block, eight particles per lane.  fminf / fmaxf drop NaN operands: a particle with a NaN coordinate draws
+// nothing and does not widen the box; infinite coordinates or smoothing lengths make the box infinite (never culled).
+__global__ __launch_bounds__(64) void block_bounds_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ z,
+                                                          const float *__restrict__ h, int64_t n, float4 *__restrict__ bounds) {
+    const int64_t b = blockIdx.x;
+    const int64_t i0 = b * BOUNDS_BLOCK;
+    const float inf = __builtin_inff();
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf}, hm = -inf;
+    for (int k = 0; k < BOUNDS_BLOCK / 64; ++k) {
+        const int64_t i = i0 + k * 64 + threadIdx.x;
+        if (i < n) {
+            const float v[3] = {x[i], y[i], z[i]};
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], v[a]); hi[a] = fmaxf(hi[a], v[a]); }
+            hm = fmaxf(hm, h[i]);
+        }
+    }
+    for (int o = 32; o; o >>= 1) {
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o)); }
+        hm = fmaxf(hm, __shfl_xor(hm, o));
+    }
+    if (threadIdx.x == 0) {
+        bounds[2 * b] = make_float4(lo[0], lo[1], lo[2], hm);
+        bounds[2 * b + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    }
+}
+
+int ensure_block_bounds(tsp_context *ctx) {
+    Workspace &ws = ctx->ws;
+    if (ws.bounds_valid) return TSP_OK;
+    const int64_t n = ctx->p.n, blocks = (n + BOUNDS_BLOCK - 1) / BOUNDS_BLOCK;
+    if (blocks == 0) return TSP_OK;
+    if (ws.bounds_capacity < blocks) {
+        if (ws.block_bounds) TSP_HIP(hipFree(ws.block_bounds));
+        ws.block_bounds = nullptr;
+        ws.bounds_capacity = blocks;
+        TSP_HIP(hipMalloc((void **)&ws.block_bounds, (size_t)blocks * 2 * sizeof(float4)));
+    }
+    hipLaunchKernelGGL(block_bounds_kernel, dim3((unsigned)blocks), dim3(64), 0, ctx->stream, ctx->p.x, ctx->p.y, ctx->p.z, ctx->p.h, n,
+                       ws.block_bounds);
+    TSP_HIP(hipGetLastError());
+    ws.bounds_valid = true;
     return TSP_OK;
 }
 
@@ -205,6 +253,7 @@ __global__ void key_prefix_offsets_kernel(const uint64_t *__restrict__ keys, int
 int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out) {
     Particles &p = ctx->p;
     const int64_t n = p.n;
+    ctx->ws.bounds_valid = false;
     hipStream_t st = ctx->stream;
     float lo[3], inv[3];
     {   // bounding box of the positions

@@ -253,7 +253,7 @@ int tsp_group_get_stats(tsp_group *grp, tsp_stats *out) {
         t.n_particles += s.n_particles; t.n_small += s.n_small; t.n_mid += s.n_mid; t.n_huge += s.n_huge; t.n_culled += s.n_culled;
         t.n_fragments += s.n_fragments; t.n_mega += s.n_mega;
         t.n_fragments_stream += s.n_fragments_stream; t.n_fragments_mid += s.n_fragments_mid;
-        t.n_fragments_huge += s.n_fragments_huge; t.n_fragments_mega += s.n_fragments_mega;
+        t.n_fragments_huge += s.n_fragments_huge; t.n_fragments_mega += s.n_fragments_mega; t.n_chunk_culled += s.n_chunk_culled;
         t.ms_stream = std::max(t.ms_stream, s.ms_stream); t.ms_mid = std::max(t.ms_mid, s.ms_mid);
         t.ms_huge = std::max(t.ms_huge, s.ms_huge); t.ms_mega = std::max(t.ms_mega, s.ms_mega);
         t.ms_total = std::max(t.ms_total, s.ms_total);

@@ -41,6 +41,10 @@ struct Particles {
     uint32_t *perm = nullptr;                // new -> old index after tsp_reorder_spatial (else nullptr)
 };
 
+// Bounds of every block of BOUNDS_BLOCK consecutive particles (view culling of whole chunks, kernel S): two float4 per block,
+// (xmin, ymin, zmin, hmax) and (xmax, ymax, zmax, -).  NaN coordinates are ignored (such a particle draws nothing).
+constexpr int BOUNDS_BLOCK = 512;            // = CHUNK of tsp_pipeline.hip (static_assert there)
+
 // Deferred-footprint record written by the streaming kernel for the tile kernels (20 B).
 struct Record {
     float pcx, pcy, P, w0, w1;
@@ -66,6 +70,11 @@ struct Workspace {     // per-context scratch of the three-class pipeline (grown
     int *band_count = nullptr;          // per image band (<= 32 bands of whole tile rows): chunks whose mid footprints reach it
     int64_t band_capacity = 0;          // slots per band
     int *band_list = nullptr;           // [32][seg_capacity] chunk indices, appended by kernel S in arrival order
+    float4 *block_bounds = nullptr;     // chunk culling: bounds of every BOUNDS_BLOCK particles (valid while bounds_valid)
+    int64_t bounds_capacity = 0;        // blocks
+    bool bounds_valid = false;          // cleared whenever positions / smoothing lengths change (upload, generate, reorder)
+    int *alive_list = nullptr;          // chunk culling: the chunks of this render call that may reach the view (seg_capacity entries)
+    unsigned long long *cull_info = nullptr;   // [0] chunks alive, [1] particles in culled chunks
     int64_t *range_prefix = nullptr;    // device copy of the ranges of the current call
     int64_t range_capacity = 0;
     int *count_diff = nullptr;          // rgb: (R+1)^2 corner-difference image of the huge footprints' pixel rectangles
@@ -134,6 +143,9 @@ struct tsp_context {
     int huge_variant = 1;             // 0: kernel H (per-pixel gather, A/B only), 1: kernels H2 (64x16 strips) + H3, 2: H2 with 64x32 strips (density)
     int mid_split = 128, huge_split = 0, mega_split = 0;  // workgroups per image tile (0 = auto)
     int stream_blocks_per_cu = 100;  // kernel S grid bound: ~10 chunks per workgroup at 1e8 particles balances dense and sparse chunks
+    bool chunk_cull = true;           // chunks (512 consecutive particles) whose bounds lie outside the view are skipped by kernel S
+                                      // unread: pays with a load-time spatial order (tsp_reorder_spatial); identical results
+    int64_t chunk_culled_particles = 0;   // of the last render call
     bool overlap_mid_huge = false;    // option: kernels M and H on two streams (measured: no gain at 1.25e8, +6 % at 1e7)
     bool debug_no_raster = false;    // measurement aid: kernel S classifies and emits records but rasterises nothing (the image is then incomplete)
     int debug_extra_lds = 0;         // measurement aid: extra dynamic LDS per workgroup of kernel M (lowers its occupancy)
@@ -172,6 +184,7 @@ int launch_colormap_bivariate(tsp_context *ctx, const float *d_img, int64_t npix
 int generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int64_t count, uint64_t seed,
                        float h_cap, int with_quantity, int with_rgb);
 int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out);
+int ensure_block_bounds(tsp_context *ctx);     // (re)computes ws.block_bounds on ctx->stream when the particles changed
 int measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, double *gbps_out);
 int launch_image_convert(tsp_context *ctx, bool to_float);
 int tile_periodic(tsp_context *ctx, int n, const float *h_offsets, const float *h_weights);

@@ -34,7 +34,7 @@ import numpy as np
 from . import _native, distributed
 
 _COUNT_KEYS = ("n_particles", "n_small", "n_mid", "n_huge", "n_culled", "n_fragments", "n_mega",
-               "n_fragments_stream", "n_fragments_mid", "n_fragments_huge", "n_fragments_mega")
+               "n_fragments_stream", "n_fragments_mid", "n_fragments_huge", "n_fragments_mega", "n_chunk_culled")
 
 
 class MultiGpuContext:
