@@ -96,7 +96,7 @@ def num_strata(n):
     return ParticleBuffers._num_strata(n)
 
 
-def profile_entry(prof, kernel, mode):
+def profile_entry(prof, kernel, mode, section="per_kernel"):
     """The PMC entry of `kernel` for the instantiation the headline frames run (MODE, channels = the first two
     template arguments): exactly one key may match, else None -- never 'the last one that contains the name'."""
     tmpl_mode = 2 if mode == "rgb" else 0
@@ -104,7 +104,7 @@ def profile_entry(prof, kernel, mode):
     if kernel == "splat_mega64_kernel":      # <MODE, waves per SIMD>: density only
         first = None
     hits = []
-    for k, v in prof.get("per_kernel", {}).items():
+    for k, v in prof.get(section, {}).items():
         name, _, args = k.partition("<")
         if name.split("::")[-1] != kernel:
             continue
@@ -312,12 +312,14 @@ def main():
     mega_kernel = "splat_mega_kernel"
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", "latest_bench_counters.json")))
-        if prof.get("bench_line", {}).get("config", {}).get("workload") == workload_name:
-            traffic_kernel, v = profile_entry(prof, dom, args.mode)
-            if v is not None:
+        option = f", option p_mega_px = {args.p_mega_px}" if args.p_mega_px else ""
+        section = "mfma_option_per_kernel" if args.p_mega_px == 768 else "per_kernel"      # (the option's own PMC pass: tools/profile_bench.sh)
+        if prof.get("bench_line", {}).get("config", {}).get("workload") == workload_name.replace(option, "") and (section != "per_kernel" or not option):
+            traffic_kernel, v = profile_entry(prof, dom, args.mode, section)
+            if v is not None and "hbm_read_bytes_corrected" in v:
                 traffic = (v.get("hbm_read_bytes_corrected", 0.0) + v.get("hbm_write_bytes", 0.0)) / 1e9
             for mega_name in ("splat_mega64_kernel", "splat_mega_kernel"):      # 64 x 64 or 64 x 32 strips, whichever ran
-                _, v = profile_entry(prof, mega_name, args.mode)
+                _, v = profile_entry(prof, mega_name, args.mode, section)
                 if v is not None and v.get("SQ_INSTS_MFMA"):
                     mfma_per_launch, mega_kernel = v["SQ_INSTS_MFMA"], mega_name
                     break

@@ -26,4 +26,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/shard_trace -o run 
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/shard_pmc_fetch -o run -- python3 bench.py $ARGS $S $P > $OUT/shard_pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/shard_pmc_write -o run -- python3 bench.py $ARGS $S $P > $OUT/shard_pmc_write.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $OUT/shard_pmc_sq -o run -- python3 bench.py $ARGS $S $P > $OUT/shard_pmc_sq.log 2>&1
+# the matrix-core option (kernel H3 from 768 px, the default of round 4) on the headline snapshot: its kernel times and MFMA counts
+X="--p-mega-px 768"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mfma_trace -o run -- python3 bench.py $ARGS $X --headline-only > $OUT/mfma_trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $OUT/mfma_pmc_sq -o run -- python3 bench.py $ARGS $X $P > $OUT/mfma_pmc_sq.log 2>&1
 find $OUT -name "*.csv" | head -30
