@@ -17,9 +17,11 @@ CELL_LAYOUT_FRACTIONAL_PADDING = 1e-5  # config.py:33
 # index prefixes stay unbiased samples at 1/STRATA granularity while runs stay screen-coherent.
 SPATIAL_ORDER_STRATA = 32
 # large snapshots get more strata so that a stratum -- the smallest spatially unbiased block of the progressive
-# renderer -- holds at most about this many particles (a 4e6-particle block renders in ~4 ms on an MI355X, well
-# inside the 1/30 s frame budget; fewer, larger strata keep 512-particle chunks more local on screen)
-MAX_PARTICLES_PER_STRATUM = 4_000_000
+# renderer -- holds at most about this many particles: 3.2e7 particles render in ~6 ms on an MI355X, well inside the
+# 1/30 s frame budget.  Fewer, larger strata keep 512-particle chunks more local on screen: the 1e9-particle snapshot in
+# 32 strata renders in 65.8 ms, in 250 (the 4e6-particle strata of rounds 1-4) 67.4 ms (kernel M 16.2 / 17.6 ms); 16 cost
+# kernel S 1.2 ms (more same-pixel collisions in its LDS window)
+MAX_PARTICLES_PER_STRATUM = 32_000_000
 SPATIAL_ORDER_MAX_STRATA = 400
 # Footprints at least this many pixels wide take kernel I (csrc/tsp_integrated.hip: second differences + two prefix sums of
 # the image) instead of the per-pixel kernels.  0 = off (the default: its result is exact to ~1e-6 of a footprint's PEAK
