@@ -17,13 +17,18 @@ N_total^-1/3) holds at every N, so value(N) / value(1) is a speed-up of the same
 lines rank 0 also times the whole snapshot on its own GPU afterwards and reports `speedup_vs_1gpu_same_snapshot`.
 `--particles-per-gpu X` selects the old weak series instead (n_total = X * N; its h-law changes with N).
 
-Prints ONE JSON line on rank 0 with the contract's keys plus `roofline` (dominant kernel against HBM, timed with
-hipEvents on the stream it runs on), `roofline_fragment` (the frame and every kernel against the f32 vector peak, priced by
-the fragments they draw: the bound that actually decides this workload), `roofline_mega` (the matrix-core kernel: issued
-and USEFUL flops) and `cpu_baseline` (the CPU oracle, kind "port", on a bounded uniform sample of the same snapshot on the
-host cores; `pynbody.sph.image` beside it when pynbody can be imported).  At N = 1 the line also carries driver-timed
-extras: BASELINE configs[1] (1e7 weighted), configs[2] (exactly 1e8), configs[4] (5e7 rgb, 2048^2), one 1.25e8-particle
-shard of the snapshot (the headline of rounds 1-3), its h-capped bandwidth regime and the option integrated_px.
+Prints ONE JSON line on rank 0 with the contract's keys plus `roofline` (HBM: the frame and kernel S -- the one kernel that
+streams the particles -- first, then every kernel with ITS OWN algorithmic bytes, PMC traffic and traffic / algorithmic;
+durations from hipEvents on the stream the kernels run on), `roofline_fragment` (the frame and every kernel against the f32
+vector peak, priced by the fragments they draw: the bound that decides kernels M and H2) and `cpu_baseline` (the CPU oracle,
+kind "port", on a bounded uniform sample of the same snapshot on the host cores; `pynbody.sph.image` beside it when pynbody
+can be imported).  At N = 1 the line also carries driver-timed extras: `shards_of_1e9_x8` (the 8 REAL index-range shards of
+the snapshot, one after another on this GPU: per-shard frame, max / mean, and the projected 1 -> 8 speed-up), the product
+path through the Visualizer (`visualizer_export_frame`, `interactive_frame`), BASELINE configs[1] (1e7 weighted), configs[2]
+(exactly 1e8), configs[4] (5e7 rgb, 2048^2), a stand-alone 1.25e8-particle snapshot (the headline of rounds 1-3), its
+h-capped bandwidth regime and the option integrated_px.  At N > 1 the line is self-validating: before timing a
+rank-dependent constant image is reduced and checked (`reduce_selftest`), after timing the reduced frame is compared with
+the same snapshot rendered whole on rank 0's GPU (`reduce_check`); a failure exits non-zero.
 
 At N = 1 the process never imports torch (north_star: no PyTorch on this path); torch.distributed is used at
 N > 1 only, as the launcher's rendezvous for the 128-byte RCCL id, the barrier and the max-over-ranks time.
@@ -41,13 +46,16 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_COPY_GBPS = 6290.0 # MI355X_MICROARCH.md: 6.29 TB/s measured (float4 copy)
-MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, 64 FLOP/clk/SIMD
 VALU_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32 vector peak (256 CUs x 4 SIMDs x 64 lanes x 2 flop x 2.4 GHz)
-# canonical arithmetic of one fragment: bilinear (P >= 64 px: kernels H / H2 / H3) acc += gy*top + fy*bot
+# canonical arithmetic of one fragment: bilinear (P >= 64 px: kernel H2; kernel I as an option) acc += gy*top + fy*bot
 # = 2 FMAs once the x-interpolated texel rows exist; nearest (kernels S / M) one multiply-add of the texel into the pixel
 FMAS_PER_FRAGMENT = {"stream": 1, "mid": 1, "huge": 2, "mega": 2}
 B_ALG = {"density": 20, "weighted": 24, "rgb": 28}     # algorithmic bytes/particle
-KERNELS = ("stream", "mid", "huge", "mega")
+KERNELS = ("stream", "mid", "huge", "mega")        # tsp_stats names: kernels S, M, H2 and (option integrated_px only) I
+KERNEL_SYMBOL = {"stream": "splat_stream_kernel", "mid": "splat_mid_kernel", "huge": "splat_huge2_kernel"}
+# one ncclReduce of the R^2 x C float32 image onto the root over xGMI (ring: 7 steps of 1/8 of the image per link, ~153 GB/s per
+# link and ~20 us per step): an ESTIMATE -- no multi-GPU box was available to this build -- used only by `projected_speedup_1to8`
+REDUCE_ESTIMATE_MS = 0.3
 
 
 def parse():
@@ -70,13 +78,11 @@ def parse():
     ap.add_argument("--no-reorder", action="store_true")
     ap.add_argument("--integrated-px", type=int, default=0,
                     help="option integrated_px of the library (kernel I for footprints at least this wide); 0 = the default path")
-    ap.add_argument("--p-mega-px", type=int, default=0,
-                    help="option p_mega_px / p_mega2_px of the library: footprints at least this wide go to the matrix-core kernel "
-                         "H3 (0 = the default since the end of round 4: kernel H2 draws every footprint >= 64 px)")
     ap.add_argument("--shared-device-dry-run", action="store_true",
                     help="harness test on a 1-GPU box: every rank uses device 0 and the image reduce is skipped (RCCL refuses two "
-                         "ranks on one device), so the launcher logic of an N > 1 run -- rendezvous, shards, barriers, the "
-                         "max-over-ranks time, the JSON line -- can be exercised; the line is marked and its value means nothing")
+                         "ranks on one device) -- the shard images are summed on the host instead, through the same self-test and "
+                         "reduce_check -- so the launcher logic of an N > 1 run (rendezvous, shards, barriers, the max-over-ranks "
+                         "time, the checks, the JSON line) can be exercised; the line is marked and its value means nothing")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline frames: no extra configurations, no CPU baseline (what the profiler runs, so "
                          "that every kernel instance in a profile belongs to the headline workload)")
@@ -101,8 +107,6 @@ def profile_entry(prof, kernel, mode, section="per_kernel"):
     template arguments): exactly one key may match, else None -- never 'the last one that contains the name'."""
     tmpl_mode = 2 if mode == "rgb" else 0
     first = {"density": "1", "weighted": "2", "rgb": None}[mode]
-    if kernel == "splat_mega64_kernel":      # <MODE, waves per SIMD>: density only
-        first = None
     hits = []
     for k, v in prof.get(section, {}).items():
         name, _, args = k.partition("<")
@@ -132,8 +136,6 @@ def make_context(_native, mips, R, channels, device, n_total, first, count, args
                            with_quantity=mode_name == "weighted", with_rgb=mode_name == "rgb")
     if not args.no_reorder:
         ctx.reorder_spatial(num_strata(count), 1337)       # load-time ordering, as the product path does
-    if args.p_mega_px:
-        ctx.set_option("p_mega_px", args.p_mega_px); ctx.set_option("p_mega2_px", args.p_mega_px)
     return ctx
 
 
@@ -243,6 +245,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    selftest = None
+    if world > 1:
+        selftest = reduce_selftest(ctx, dist, torch, rank, world, use_comm, R, channels)
+
     for _ in range(args.warmup):
         frame(False)
     barrier()
@@ -259,7 +265,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- N > 1: the reduced frame, for the check against the whole snapshot below (one more frame, untimed) ----------
+    reduced_image = None
+    if world > 1:
+        frame(False)
+        reduced_image = collect_reduced_image(ctx, dist, torch, rank, world, use_comm)
+
     frags, frags_by_kernel = count_fragments(ctx, M, sf, mode, flags)
+    records = ctx.stats()          # class counts of this rank's shard (identical every frame)
     # the slowest shard decides the frame: per-kernel times of every rank (strong scaling: how even the shards are)
     means = {k: float(np.mean(v)) if v else 0.0 for k, v in kernel_ms.items()}
     per_rank_ms = None
@@ -276,25 +289,16 @@ def main():
     if rank != 0:
         if dist is not None:
             dist.barrier()           # rank 0 times the whole snapshot on one GPU meanwhile
+            ok = torch.zeros(1, dtype=torch.int32)
+            dist.broadcast(ok, src=0)
             dist.destroy_process_group()
+            if int(ok.item()) != 1:
+                sys.exit(3)
         return
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total / (elapsed / args.steps)
     ms_median = float(np.median(step_s)) * 1e3
-    # dominant kernel of the frame and its roofline (HBM: B_alg bytes/particle streamed once)
-    parts = {k: means[k] for k in KERNELS}
-    if sum(parts.values()) <= 0.0:
-        dom, dom_ms = "splat_generic_kernel", means["total"]
-    else:
-        dom = max(parts, key=parts.get)
-        dom_ms = parts[dom]
-        dom = {"stream": "splat_stream_kernel", "mid": "splat_mid_kernel",
-               "mega": "splat_mega64_kernel" if args.mode == "density" else "splat_mega_kernel",
-               "huge": "splat_huge2_kernel"}[dom]
-    bytes_per_launch = B_ALG[args.mode] * n_per
-    achieved = bytes_per_launch / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    stream_ms = means["stream"] if means["stream"] > 0 else means["total"]
     config_tag = " = BASELINE.json configs[3]" if (n_total == 10**9 and args.mode == "density" and R == 1024 and not weak
                                                     and args.h_cap_px <= 0) else ""
     workload_name = (f"{n_total:.4g} dm particles{config_tag}, {args.mode}, {R}^2 buffer, camera A "
@@ -302,29 +306,15 @@ def main():
                      + (f"index-range sharded x{world} ({n_per:.4g}/GPU)" if world > 1 else "whole snapshot resident on one GPU")
                      + (f", h capped at {args.h_cap_px:g} px" if args.h_cap_px > 0 else "")
                      + (f", option integrated_px = {args.integrated_px}" if args.integrated_px else "")
-                     + (f", option p_mega_px = {args.p_mega_px}" if args.p_mega_px else "")
                      + ", splat + " + ("RCCL image reduce + " if world > 1 else "") + "colormap")
     measured_peak = ctx.measure_read_bandwidth(4 << 30, 5)
-    # HBM bytes of the dominant kernel from the PMC passes committed under profiles/ (FETCH_SIZE doubled as
-    # MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE); null when no profile matches this workload
-    traffic = traffic_kernel = None
-    mfma_per_launch = None      # v_mfma_f32_* instructions of kernel H3 per launch (PMC SQ_INSTS_MFMA)
-    mega_kernel = "splat_mega_kernel"
-    try:
+    prof = None
+    try:       # PMC passes committed under profiles/ (tools/profile_bench.sh): only when they were taken on THIS workload
         prof = json.load(open(os.path.join(ROOT, "profiles", "latest_bench_counters.json")))
-        option = f", option p_mega_px = {args.p_mega_px}" if args.p_mega_px else ""
-        section = "mfma_option_per_kernel" if args.p_mega_px == 768 else "per_kernel"      # (the option's own PMC pass: tools/profile_bench.sh)
-        if prof.get("bench_line", {}).get("config", {}).get("workload") == workload_name.replace(option, "") and (section != "per_kernel" or not option):
-            traffic_kernel, v = profile_entry(prof, dom, args.mode, section)
-            if v is not None and "hbm_read_bytes_corrected" in v:
-                traffic = (v.get("hbm_read_bytes_corrected", 0.0) + v.get("hbm_write_bytes", 0.0)) / 1e9
-            for mega_name in ("splat_mega64_kernel", "splat_mega_kernel"):      # 64 x 64 or 64 x 32 strips, whichever ran
-                _, v = profile_entry(prof, mega_name, args.mode, section)
-                if v is not None and v.get("SQ_INSTS_MFMA"):
-                    mfma_per_launch, mega_kernel = v["SQ_INSTS_MFMA"], mega_name
-                    break
+        if prof.get("bench_line", {}).get("config", {}).get("workload") != workload_name:
+            prof = None
     except Exception:
-        pass
+        prof = None
     result = {
         "metric": "particles/sec splatted to 1024^2 buffer",
         "value": value, "unit": "particles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -332,72 +322,58 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload_name, "total_particles": n_total,
                    "particles_per_gpu": n_per, "resolution": R, "sharding": f"index-range x{world}",
-                   "pipeline": "generic" if args.generic else ("four-class (stream / mid scatter / row-uniform gather / MFMA)" if args.p_mega_px
-                                                               else "three-class (stream / mid scatter / row-uniform gather)"),
+                   "pipeline": "generic" if args.generic else "three-class (stream / mid scatter / row-uniform gather)",
                    "fragments_per_particle": frags / n_total, "frames_per_s": 1e3 / ms_per_step},
         "ms_per_step_median": ms_median, "value_at_median": n_total / (ms_median * 1e-3),
         "fragments_per_s": frags / (ms_per_step * 1e-3),
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_unit": "GB per launch (PMC)",
-                     "traffic_kernel": traffic_kernel, "kernel_ms": dom_ms,
-                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "measured_read_peak_GBps": measured_peak, "guide_measured_copy_GBps": HBM_MEASURED_COPY_GBPS,
-                     "stream_kernel_ms": stream_ms,
-                     "stream_kernel_GBps": bytes_per_launch / (stream_ms * 1e-3) / 1e9 if stream_ms > 0 else 0.0,
-                     "stream_kernel_frac": bytes_per_launch / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if stream_ms > 0 else 0.0,
-                     "frame_GBps": B_ALG[args.mode] * n_total / (ms_per_step * 1e-3) / 1e9,
-                     "frame_frac": B_ALG[args.mode] * n_total / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS / world,
-                     "note": "the dominant kernel is priced against HBM because the contract asks for it; it is bound by the "
-                             "fragments it draws -- see roofline_fragment"},
+        "roofline": hbm_roofline(args, means, records, n_per, n_total, world, ms_per_step, R, channels, prof, measured_peak),
         # per GPU: a rank draws 1/N of the frame's fragments (rank 0's kernel times beside the mean share)
         "roofline_fragment": fragment_roofline({k: v / world for k, v in frags_by_kernel.items()}, means, ms_per_step),
         "kernel_ms": means,
         "setup_s": t_setup,
     }
     if args.shared_device_dry_run:
-        result["dry_run"] = "ranks shared device 0 and no image reduce ran: harness test only, `value` is not a measurement"
+        result["dry_run"] = ("ranks shared device 0 and the shard images were summed on the host instead of by RCCL: harness test "
+                             "only, `value` is not a measurement")
+    ok = True
     if world > 1:
         result["roofline_fragment"]["note_n_gpus"] = (f"per GPU: 1/{world} of the frame's fragments against rank 0's kernel times "
                                                       "and the step time")
         result["per_rank_kernel_ms"] = per_rank_ms
         tot = [r["total"] for r in per_rank_ms]
         result["shard_balance_max_over_mean"] = max(tot) / (sum(tot) / len(tot)) if sum(tot) > 0 else None
-    if mfma_per_launch and means["mega"] > 0 and not args.integrated_px:
-        # the matrix-core kernel against ITS roofline: instruction count from the committed PMC pass, duration live.
-        # Issued flop count every K slot of every MFMA; useful flop are the 2 FMAs per fragment the kernel exists for.
-        issued = mfma_per_launch * 2 * 32 * 32 * 2
-        useful = float(frags_by_kernel["mega"]) * FMAS_PER_FRAGMENT["mega"] * 2.0 / world
-        tflops = issued / (means["mega"] * 1e-3) / 1e12
-        useful_tflops = useful / (means["mega"] * 1e-3) / 1e12
-        result["roofline_mega"] = {"bound": "mfma", "kernel": mega_kernel, "achieved": useful_tflops, "peak": MFMA_F32_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": useful_tflops / MFMA_F32_PEAK_TFLOPS, "kernel_ms": means["mega"],
-                                   "issued_TFLOPs": tflops, "issued_frac": tflops / MFMA_F32_PEAK_TFLOPS,
-                                   "useful_frac": useful / issued if issued > 0 else None,
-                                   "mfma_instructions_per_launch": mfma_per_launch,
-                                   "note": "achieved / frac count USEFUL flop (fragments x 2 FMAs x 2); issued_* count every K slot "
-                                           "of every v_mfma_f32_32x32x2_f32 (2 x 32 x 32 x 2 flop each)"}
+        result["reduce_selftest"] = selftest
+        ok = ok and bool(selftest.get("ok"))
     if world > 1 and not weak and not args.headline_only:
-        # the same snapshot whole on ONE GPU (rank 0's, the others wait at the barrier): what N = 1 prints as `value`
+        # the same snapshot whole on ONE GPU (rank 0's, the others wait at the barrier): what N = 1 prints as `value`, and the
+        # witness of the collective: the reduced frame must equal it within the 1e-5 of SURVEY section 8e
         try:       # (a second context next to this rank's shard: the communicator stays up until every rank is done)
-            one = whole_snapshot_line(_native, mips, R, channels, local_rank, n_total, args, mode, lut, vmin, vmax)
+            one, whole_image = whole_snapshot_line(_native, mips, R, channels, local_rank, n_total, args, mode, lut, vmin, vmax)
             result["one_gpu_same_snapshot"] = one
             result["speedup_vs_1gpu_same_snapshot"] = one["ms_per_step"] / ms_per_step
+            result["reduce_check"] = compare_images(reduced_image, whole_image, world)
+            ok = ok and bool(result["reduce_check"]["ok"])
         except _native.BackendError as e:
             result["one_gpu_same_snapshot"] = {"error": str(e)[:200]}
             result["speedup_vs_1gpu_same_snapshot"] = None
-    extras = (world == 1 and not args.generic and not args.headline_only and args.h_cap_px <= 0 and not args.integrated_px
-              and not args.p_mega_px)
+            result["reduce_check"] = {"ok": False, "error": "the whole snapshot could not be rendered on rank 0: " + str(e)[:160], "ranks": world}
+            ok = False
+    extras = world == 1 and not args.generic and not args.headline_only and args.h_cap_px <= 0 and not args.integrated_px
     if extras and args.mode == "density":
+        whole_ms = ms_per_step
         if ctx is not None:
             ctx.close()
-        # one 1.25e8-particle shard of the 1e9 snapshot = the headline of rounds 1-3 (what each of 8 GPUs renders), and on it
-        # the opt-in kernel I and the bandwidth regime (the same positions with footprints capped at
-        # 8 px isolate the streaming kernels); reported beside the headline, never as `value`
+        if n_total == 10**9 and R == 1024 and not weak:
+            # config 3 as the 8 GPUs will see it: every index-range shard of THIS snapshot, one after another on this GPU
+            result["shards_of_1e9_x8"] = shards_line(_native, mips, R, local_rank, n_total, 8, args, mode, lut, vmin, vmax, whole_ms)
+        # a stand-alone 1.25e8-particle snapshot = the headline of rounds 1-3 (NOT a shard of the 1e9 snapshot: its h-law is that
+        # of N = 1.25e8), and on it the opt-in kernel I and the bandwidth regime (the same positions with
+        # footprints capped at 8 px isolate the streaming kernels); reported beside the headline, never as `value`
         n_sh = 125_000_000
         ctx = make_context(_native, mips, R, 2, local_rank, n_sh, 0, n_sh, args)
-        result["shard_1p25e8"] = config_line(ctx, n_sh, "density", R, args, "a 1.25e8-particle snapshot (the headline of "
-                                             "rounds 1-3; h-law of N = 1.25e8)", regenerate=False)
-        result["matrix_core_option"] = matrix_core_line(ctx, M, sf, mode, n_sh)
+        result["standalone_1p25e8"] = config_line(ctx, n_sh, "density", R, args, "a stand-alone 1.25e8-particle snapshot (the headline "
+                                                  "of rounds 1-3; h-law of N = 1.25e8, wider footprints than a shard of the 1e9 snapshot)",
+                                                  regenerate=False)
         result["integrated_option"] = integrated_line(ctx, M, sf, mode, n_sh)
         result["bandwidth_regime"] = hcapped_line(args, ctx, n_sh, n_sh, 0, M, sf, mode, measured_peak)
         # the other single-GPU configurations of BASELINE.json, driver-timed beside the headline (never `value`)
@@ -412,12 +388,117 @@ def main():
         result["baseline_config_4"] = config_line(c5, 50_000_000, "rgb", 2048, args,
                                                   "BASELINE.json configs[4]: 5e7 star particles, rgb, 2048^2")
         c5.close()
+        # the product path: the same frames through the Visualizer / SPH / ColormapHolder surface (reference visualizer.py, sph.py:306-332)
+        result["visualizer_export_frame"] = visualizer_lines(local_rank, R, args, whole_ms, n_total if (n_total == 10**9 and not weak) else None)
+        result["interactive_frame"] = interactive_line(local_rank, R, args)
     if not args.no_cpu_baseline and not args.headline_only and world == 1:      # reported baseline: rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(args, n_total, M, sf, R)
     print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.broadcast(flag, src=0)
         dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)       # (a fresh exit of this process; nothing is re-executed)
+
+
+def hbm_roofline(args, means, records, n_per, n_total, world, ms_per_step, R, channels, prof, measured_peak):
+    """The HBM view of the frame.  First the two figures that mean something against the 8 TB/s roof: the
+    FRAME (B_alg bytes per particle over the whole step) and kernel S, the one kernel that streams the particles.  Then every
+    kernel with its own algorithmic bytes per launch -- S: particles x B_alg; M, H2: their records x 20 B (24 B rgb) plus one
+    float64 flush of the image -- its PMC traffic (profiles/latest_bench_counters.json: 2 x FETCH_SIZE + WRITE_SIZE, as
+    MI355X_MICROARCH.md prescribes for gfx950) and traffic / algorithmic.  Kernels M and H2 are NOT HBM kernels: their bound is
+    the fragment rate (`roofline_fragment`); their rows are here so that wasted re-reads show."""
+    b_alg = B_ALG[args.mode]
+    rec_bytes = 24 if args.mode == "rgb" else 20
+    image_bytes = R * R * channels * 8
+    alg = {"stream": b_alg * n_per,
+           "mid": int(records.get("n_mid", 0)) * rec_bytes + image_bytes,
+           "huge": int(records.get("n_huge", 0)) * rec_bytes + image_bytes}
+    per = {}
+    for k in ("stream", "mid", "huge"):
+        ms = means.get(k, 0.0)
+        traffic = name = None
+        if prof is not None:
+            name, v = profile_entry(prof, KERNEL_SYMBOL[k], args.mode)
+            if v is not None and "hbm_read_bytes_corrected" in v:
+                traffic = v.get("hbm_read_bytes_corrected", 0.0) + v.get("hbm_write_bytes", 0.0)
+        gbps = alg[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        per[k] = {"kernel": KERNEL_SYMBOL[k], "kernel_ms": ms, "algorithmic_bytes_per_launch": alg[k], "achieved": gbps,
+                  "frac": gbps / HBM_PEAK_GBPS, "traffic": None if traffic is None else traffic / 1e9,
+                  "traffic_over_algorithmic": None if traffic is None else traffic / max(alg[k], 1), "traffic_kernel": name}
+    s_ms = means["stream"] if means.get("stream", 0.0) > 0 else means.get("total", 0.0)      # (generic pipeline: one kernel)
+    s_gbps = alg["stream"] / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0
+    frame_gbps = b_alg * n_total / (ms_per_step * 1e-3) / 1e9 / world
+    by_time = max(("stream", "mid", "huge"), key=lambda k: means.get(k, 0.0))
+    return {"bound": "hbm", "kernel": KERNEL_SYMBOL["stream"], "achieved": s_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": s_gbps / HBM_PEAK_GBPS, "traffic": per["stream"]["traffic"], "traffic_unit": "GB per launch (PMC)",
+            "kernel_ms": s_ms, "algorithmic_bytes_per_launch": alg["stream"],
+            "frame": {"achieved": frame_gbps, "frac": frame_gbps / HBM_PEAK_GBPS, "ms": ms_per_step,
+                      "algorithmic_bytes_per_gpu": b_alg * n_per, "north_star_target_frac": 0.40},
+            "per_kernel": per, "longest_kernel": KERNEL_SYMBOL[by_time],
+            "measured_read_peak_GBps": measured_peak, "guide_measured_copy_GBps": HBM_MEASURED_COPY_GBPS,
+            "frac_of_measured_read_peak": s_gbps / measured_peak if measured_peak else None,
+            "note": "kernel S is the path's HBM-shaped kernel (it streams every particle once); the longest kernel is bound by the "
+                    "fragments it draws, not by bytes -- see roofline_fragment.per_kernel"}
+
+
+# ---- N > 1: self-validation of the one collective of the path ---------------------------------------------------------
+def selftest_pattern(R, channels, rank):
+    """rank-dependent image of small integers: any sum over <= 64 ranks is exact in float32"""
+    j, i = np.meshgrid(np.arange(R), np.arange(R), indexing="ij")
+    base = ((i + 2 * j) % 7 + 1).astype(np.float32)
+    return np.stack([base * (rank + 1) + c for c in range(channels)], axis=-1).astype(np.float32)
+
+
+def host_sum(img, dist, torch, rank, world):
+    """the shard images summed on rank 0 through the rendezvous group (stand-in for the RCCL reduce in --shared-device-dry-run)"""
+    t = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))
+    parts = [torch.zeros_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, parts, dst=0)
+    if rank != 0:
+        return None
+    acc = np.zeros(img.shape, dtype=np.float32)
+    for q in parts:                       # rank order, float32: what ncclReduce(sum, float32) computes up to association
+        acc += q.numpy()
+    return acc
+
+
+def reduce_selftest(ctx, dist, torch, rank, world, use_comm, R, channels):
+    """Every rank writes a rank-dependent constant image, ONE reduce, rank 0 checks the exact sum."""
+    ctx.write_image(selftest_pattern(R, channels, rank))
+    if use_comm:
+        ctx.comm_reduce_image(root=0)
+        got = ctx.read_image() if rank == 0 else None
+    else:
+        got = host_sum(ctx.read_image(), dist, torch, rank, world)
+    if rank != 0:
+        return None
+    want = np.zeros((R, R, channels), dtype=np.float64)
+    for r in range(world):
+        want += selftest_pattern(R, channels, r)
+    bad = int((got.astype(np.float64) != want).sum())
+    return {"ok": bad == 0, "ranks": world, "pixels_wrong": bad, "collective": "ncclReduce(sum, float32) over RCCL" if use_comm
+            else "host sum over the rendezvous group (dry run: ranks share one device)"}
+
+
+def collect_reduced_image(ctx, dist, torch, rank, world, use_comm):
+    """the frame rank 0 presents: after the RCCL reduce it is rank 0's render target; in the dry run the host sum of the shards"""
+    if use_comm:
+        return ctx.read_image() if rank == 0 else None
+    return host_sum(ctx.read_image(), dist, torch, rank, world)
+
+
+def compare_images(reduced, whole, world, rtol=1e-5):
+    """reduced frame of N shards against the same snapshot whole on one GPU: 1e-5 relative per pixel"""
+    a, b = reduced.astype(np.float64), whole.astype(np.float64)
+    lit = b != 0
+    rel = np.abs(a - b)[lit] / np.abs(b[lit])
+    dark_ok = bool((a[~lit] == 0).all())
+    max_rel = float(rel.max()) if rel.size else 0.0
+    return {"ok": bool(max_rel <= rtol and dark_ok and lit.any()), "max_rel": max_rel, "rtol": rtol, "ranks": world,
+            "pixels_compared": int(lit.sum()), "zero_pixels_stay_zero": dark_ok}
 
 
 def whole_snapshot_line(_native, mips, R, channels, device, n_total, args, mode, lut, vmin, vmax, frames=5):
@@ -438,39 +519,140 @@ def whole_snapshot_line(_native, mips, R, channels, device, n_total, args, mode,
         one()
     ms = (time.perf_counter() - t) / frames * 1e3
     st = c.stats()
+    image = c.read_image()
     c.close()
     return {"workload": f"the same {n_total:.4g}-particle snapshot whole on one GPU", "ms_per_step": ms,
             "value": n_total / (ms * 1e-3), "unit": "particles/s", "frames": frames,
-            "kernel_ms": {k: st["ms_" + k] for k in KERNELS}}
+            "kernel_ms": {k: st["ms_" + k] for k in KERNELS}}, image
 
 
-def matrix_core_line(ctx, M, sf, mode, n_per, px=768, frames=10):
-    """The frame with kernel H3 (v_mfma_f32_32x32x2_f32) drawing the footprints >= px -- the default of rounds 2-4 -- beside the
-    default path, whose kernel H2 draws them: why the matrix cores are an option now."""
-    def run():
-        ms, h2, h3 = [], [], []
-        for i in range(frames + 1):
-            t = ctx.render(M, sf, clear=True, mode=mode)
-            if i:
-                st = ctx.stats(); ms.append(t); h2.append(st["ms_huge"]); h3.append(st["ms_mega"])
-        return float(np.median(ms)), float(np.median(h2)), float(np.median(h3))
-    ms0, h20, _ = run()
-    _, by0 = count_fragments(ctx, M, sf, mode)
-    ctx.set_option("p_mega_px", px)
-    ms1, h21, h31 = run()
-    _, by1 = count_fragments(ctx, M, sf, mode)
-    n_mega = int(ctx.stats()["n_mega"])
-    ctx.set_option("p_mega_px", 0)
-    useful = float(by1["mega"]) * FMAS_PER_FRAGMENT["mega"] * 2.0
-    return {"workload": f"the 1.25e8-particle snapshot with the option p_mega_px = {px} (footprints >= {px} px through kernel H3)",
-            "ms_per_step": ms1, "ms_per_step_default_path": ms0, "value": n_per / (ms1 * 1e-3), "unit": "particles/s",
-            "kernel_H2_ms": h21, "kernel_H3_ms": h31, "kernel_H2_ms_default_path": h20, "records_through_kernel_H3": n_mega,
-            "fragments_through_kernel_H3": int(by1["mega"]),
-            "kernel_H2_ms_for_the_same_fragments": h20 - h21,
-            "roofline_mega": {"bound": "mfma", "achieved": useful / (h31 * 1e-3) / 1e12 if h31 > 0 else 0.0, "peak": MFMA_F32_PEAK_TFLOPS,
-                              "unit": "TFLOP/s", "frac": useful / (h31 * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if h31 > 0 else 0.0,
-                              "note": "useful flop (fragments x 2 FMAs x 2); f32 MFMA and packed-f32 VALU share one peak on gfx950, and "
-                                      "the GEMM form issues 1.9x the useful flop (profiles/round4d: useful_frac 0.52, issued_frac 0.50)"}}
+def shards_line(_native, mips, R, device, n_total, G, args, mode, lut, vmin, vmax, whole_ms, frames=6):
+    """BASELINE config 3 as its 8 GPUs will see it, on the one GPU at hand: every index-range shard [g N / G, (g + 1) N / G)
+    of THE snapshot (split_buffers.py:26-38) is generated, ordered and rendered in turn -- no fragment counting, wall clock around
+    the synchronous tsp_render as in the headline -- and the 8-GPU frame is projected as the slowest shard + one image reduce
+    (an estimate: REDUCE_ESTIMATE_MS) + the colormap on the root."""
+    M, sf = camera(args.scale)
+    ctx = _native.Context(R, 2, device_id=device)
+    ctx.set_kernel_mips(mips)
+    per, cmap_ms = [], None
+    for g in range(G):
+        first, cnt = shard_range(n_total, G, g)
+        ctx.generate_synthetic(n_total, first=first, count=cnt, seed=1337, h_cap=0.0)
+        if not args.no_reorder:
+            ctx.reorder_spatial(num_strata(cnt), 1337)
+        ms, kms = [], {k: [] for k in KERNELS}
+        for i in range(frames + 2):
+            t = time.perf_counter()
+            ctx.render(M, sf, clear=True, mode=mode)
+            dt = (time.perf_counter() - t) * 1e3
+            if i >= 2:
+                ms.append(dt)
+                st = ctx.stats()
+                for k in KERNELS:
+                    kms[k].append(st["ms_" + k])
+        if cmap_ms is None:
+            ts = []
+            for _ in range(5):
+                t = time.perf_counter()
+                ctx.colormap_scalar(lut, vmin, vmax, True, False)
+                ts.append((time.perf_counter() - t) * 1e3)
+            cmap_ms = float(np.median(ts))
+        st = ctx.stats()
+        per.append({"shard": g, "first": first, "particles": cnt, "ms_per_step": float(np.median(ms)),
+                    "kernel_ms": {k: float(np.median(v)) for k, v in kms.items() if k != "mega"},
+                    "records": {"small": int(st["n_small"]), "mid": int(st["n_mid"]), "huge": int(st["n_huge"]), "culled": int(st["n_culled"])}})
+    ctx.close()
+    t = [x["ms_per_step"] for x in per]
+    slowest, mean = max(t), sum(t) / len(t)
+    step8 = slowest + REDUCE_ESTIMATE_MS + cmap_ms
+    return {"workload": f"the {G} index-range shards of the {n_total:.4g}-particle snapshot (what each of {G} GPUs holds), one after "
+                        f"another on this GPU, {R}^2, camera A", "per_shard": per, "max_shard_ms": slowest, "mean_shard_ms": mean,
+            "max_over_mean": slowest / mean, "sum_of_shards_ms": sum(t), "colormap_ms": cmap_ms,
+            "reduce_estimate_ms": REDUCE_ESTIMATE_MS, "whole_snapshot_on_one_gpu_ms": whole_ms,
+            "projected_ms_per_step_8gpu": step8, "projected_speedup_1to8": whole_ms / step8,
+            "projected_frames_per_s_8gpu": 1e3 / step8, "north_star_target_speedup": 6.0,
+            "note": "projection = whole-snapshot step on one GPU / (slowest shard + reduce estimate + colormap); the reduce term is an "
+                    "estimate (no multi-GPU box was available to this build), everything else is measured here"}
+
+
+def visualizer_lines(device, R, args, whole_ms, n_big=None, frames=5):
+    """The drop-in path: Visualizer.get_sph_presentation_image() = SPH.render(EXPORT) + ColormapHolder pass (reference
+    visualizer.py:456-474, sph.py:306-332) on a device-generated snapshot, beside the bare C-ABI frame (tsp_render of everything +
+    tsp_colormap_scalar) on the SAME context.  EXPORT is one block on this backend (config.MAX_PARTICLES_PER_EXPORT_RENDERCALL)."""
+    import topsy_amd
+    from topsy_amd import DrawReason
+    out = []
+    for n in [100_000_000] + ([n_big] if n_big else []):
+        try:
+            t0 = time.perf_counter()
+            vis = topsy_amd.synthetic_on_device(n, render_resolution=R, device_id=device)
+            setup = time.perf_counter() - t0
+            vis.get_sph_presentation_image()
+            ts = []
+            for _ in range(frames):
+                t = time.perf_counter()
+                img = vis.get_sph_presentation_image()
+                ts.append((time.perf_counter() - t) * 1e3)
+            blocks = getattr(vis._sph, "last_render_blocks", None)
+            ctx = vis.particle_buffers.context
+            M, sf = vis._sph._transform
+            params = vis.colormap.get_parameters()
+            import matplotlib
+            lut = matplotlib.colormaps[params["colormap_name"]](np.linspace(0.001, 0.999, 1000)).astype(np.float32)
+            tc = []
+            for _ in range(frames + 1):
+                t = time.perf_counter()
+                ctx.render(M, sf, clear=True, mode=vis._sph._mode)
+                ctx.colormap_scalar(lut, float(params["vmin"]), float(params["vmax"]), bool(params["log"]), False)
+                tc.append((time.perf_counter() - t) * 1e3)
+            vis_ms, cabi_ms = float(np.median(ts)), float(np.median(tc[1:]))
+            line = {"particles": n, "visualizer_export_frame_ms": vis_ms, "c_abi_frame_ms": cabi_ms, "ratio": vis_ms / cabi_ms,
+                    "frames_per_s": 1e3 / vis_ms, "setup_s": setup, "image_shape": list(img.shape), "image_dtype": str(img.dtype)}
+            if blocks is not None:
+                line["render_blocks_per_frame"] = blocks
+            if n == n_big:
+                line["headline_ms_per_step"] = whole_ms
+                line["ratio_to_headline"] = vis_ms / whole_ms
+            vis.close()
+            out.append(line)
+        except Exception as e:       # (never lose the bench line to an extra)
+            out.append({"particles": n, "error": f"{type(e).__name__}: {e}"[:240]})
+    return {"workload": "Visualizer.get_sph_presentation_image(): SPH.render(EXPORT) + colormap through the reference's object "
+                        f"protocol, density, {R}^2, camera A, beside tsp_render + tsp_colormap_scalar on the same context", "sizes": out}
+
+
+def interactive_line(device, R, args, n=1_000_000_000, frames=24):
+    """The regime the reference is built around (config.py:6-7: 30 frames/s, progressive blocks): Visualizer.draw(CHANGE) on the
+    1e9-particle snapshot -- one time-budgeted block + colormap per frame -- until the adaptive block size has settled: how many
+    particles a 1/30 s frame draws, and how long the frame really takes."""
+    import topsy_amd
+    from topsy_amd import DrawReason, config
+    try:
+        vis = topsy_amd.synthetic_on_device(n, render_resolution=R, device_id=device)
+        drawn, ms = [], []
+        for i in range(frames):
+            t = time.perf_counter()
+            vis.draw(DrawReason.CHANGE)
+            ms.append((time.perf_counter() - t) * 1e3)
+            drawn.append(n / vis._sph.last_render_mass_scale)
+        # REFINE frames continue from the cursor until the snapshot is complete
+        refine = 0
+        t = time.perf_counter()
+        while vis._sph.needs_refine() and refine < 1000:
+            vis.draw(DrawReason.REFINE)
+            refine += 1
+        refine_ms = (time.perf_counter() - t) * 1e3
+        vis.close()
+        tail = slice(frames // 2, None)
+        return {"workload": f"Visualizer.draw(CHANGE) on the {n:.4g}-particle snapshot, {R}^2, camera A: one progressive block of "
+                            f"the 1/{config.TARGET_FPS} s budget + colormap per frame (progressive_render.py:48-86)",
+                "particles_per_frame": float(np.median(drawn[tail])), "ms_per_frame": float(np.median(ms[tail])),
+                "frames_per_s": 1e3 / float(np.median(ms[tail])), "target_frames_per_s": config.TARGET_FPS,
+                "fraction_of_snapshot_per_frame": float(np.median(drawn[tail])) / n,
+                "first_frame_particles": drawn[0], "first_frame_ms": ms[0],
+                "refine_frames_to_complete": refine, "refine_ms_to_complete": refine_ms}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:240]}
 
 
 def integrated_line(ctx, M, sf, mode, n_per, px=256, frames=10):

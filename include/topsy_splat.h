@@ -67,7 +67,10 @@ const char *tsp_last_error(void);
  * footprint; the default moved from 13.5 to 16 px): values 16001..22627 now return TSP_EINVAL.
  * 102: tsp_stats grew by 32 bytes (n_fragments_stream / _mid / _huge / _mega appended); same rule.
  * 103: tsp_stats grew by 8 bytes (n_chunk_culled appended); same rule.  Defaults changed without an ABI change: kernel H3
- * (matrix cores) is an option ("p_mega_px" / "p_mega2_px" default to 0), chunk culling ("chunk_cull") is on. */
+ * (matrix cores) is an option ("p_mega_px" / "p_mega2_px" default to 0), chunk culling ("chunk_cull") is on.
+ * 104: the matrix-core kernels and the round-1 gather kernel are gone (no default rule selected them): the options
+ * "p_mega_px", "p_mega2_px", "p_mega_rgb_px", "mega_variant", "rgb_mega_variant" and "huge_variant" = 0 / 3 now return
+ * TSP_EINVAL; tsp_stats keeps its layout (ms_mega / n_mega / n_fragments_mega now describe kernel I only). */
 int tsp_version(void);
 int tsp_stats_size(void);
 
@@ -223,11 +226,11 @@ typedef struct {
     int64_t n_huge;        /* bilinear footprints (P >= 64 px) deferred to the tile-gather kernels (incl. n_mega) */
     int64_t n_culled;      /* z-slab / off-screen / non-finite */
     int64_t n_fragments;   /* pixel updates (only counted when TSP_STATS is enabled) */
-    double ms_stream, ms_mid, ms_huge, ms_total; /* per-kernel GPU time, hipEvents; ms_huge = kernel H or H2 */
-    double ms_mega;        /* kernel H3 (footprints >= p_mega px on the matrix cores); 0 when it did not run */
-    int64_t n_mega;        /* footprints handled by kernel H3 */
+    double ms_stream, ms_mid, ms_huge, ms_total; /* per-kernel GPU time, hipEvents; ms_huge = kernel H2 */
+    double ms_mega;        /* kernel I (option integrated_px: footprints at least that wide); 0 when it did not run */
+    int64_t n_mega;        /* footprints handled by kernel I */
     /* n_fragments by the kernel that drew them (counted like n_fragments; 0 on the generic pipeline): kernel S, kernel M,
-     * kernel H / H2, kernel H3 (or kernel I) -- what bench.py prices each kernel's fragment-rate roofline with */
+     * kernel H2, kernel I -- what bench.py prices each kernel's fragment-rate roofline with */
     int64_t n_fragments_stream, n_fragments_mid, n_fragments_huge, n_fragments_mega;
     /* of n_culled: particles of chunks (512 consecutive particles) whose bounding box lay outside the view -- never read
      * (option "chunk_cull", on by default; needs >= 4096 chunks in the call, pays after tsp_reorder_spatial) */

@@ -41,15 +41,45 @@ def test_profile_entry_picks_the_timed_instantiation():
         "tsp::splat_huge2_kernel<0, 1, 1, 32, 8, true>": {"x": 2},        # the one counting frame
         "tsp::splat_huge2_kernel<0, 2, 1, 16, 7, false>": {"x": 3},       # weighted
         "tsp::splat_huge2_kernel<2, 3, 1, 16, 5, false>": {"x": 4},       # rgb
-        "tsp::splat_mega64_kernel<0, 4, false>": {"x": 5},
-        "tsp::splat_mega64_kernel<0, 4, true>": {"x": 6},
         "tsp::splat_stream_kernel<0, 1>": {"x": 7}, "tsp::splat_stream_kernel<0, 2>": {"x": 8}}}
     assert bench.profile_entry(prof, "splat_huge2_kernel", "density")[1] == {"x": 1}
     assert bench.profile_entry(prof, "splat_huge2_kernel", "weighted")[1] == {"x": 3}
     assert bench.profile_entry(prof, "splat_huge2_kernel", "rgb")[1] == {"x": 4}
-    assert bench.profile_entry(prof, "splat_mega64_kernel", "density")[1] == {"x": 5}
     assert bench.profile_entry(prof, "splat_stream_kernel", "weighted")[1] == {"x": 8}
     assert bench.profile_entry(prof, "splat_mid_kernel", "density") == (None, None)
     # two candidates that cannot be told apart: no guess
     prof["per_kernel"]["tsp::splat_huge2_kernel<0, 1, 1, 16, 8, false>"] = {"x": 9}
     assert bench.profile_entry(prof, "splat_huge2_kernel", "density") == (None, None)
+
+
+def test_hbm_roofline_prices_every_kernel_with_its_own_bytes():
+    class A: mode = "density"
+    means = {"stream": 17.0, "mid": 16.0, "huge": 33.0, "total": 66.5}
+    records = {"n_mid": 24_905_644, "n_huge": 4_232_789}
+    prof = {"per_kernel": {"tsp::splat_stream_kernel<0, 1>": {"hbm_read_bytes_corrected": 20.06e9, "hbm_write_bytes": 1.49e9},
+                           "tsp::splat_huge2_kernel<0, 1, 1, 32, 8, false>": {"hbm_read_bytes_corrected": 12.73e9, "hbm_write_bytes": 11.08e9}}}
+    r = bench.hbm_roofline(A, means, records, 10**9, 10**9, 1, 67.3, 1024, 2, prof, 6660.0)
+    assert r["kernel"] == "splat_stream_kernel" and r["bound"] == "hbm" and r["longest_kernel"] == "splat_huge2_kernel"
+    assert np.isclose(r["achieved"], 20e9 / 17e-3 / 1e9) and np.isclose(r["frac"], r["achieved"] / 8000.0)
+    assert np.isclose(r["frame"]["achieved"], 20e9 / 67.3e-3 / 1e9)
+    h = r["per_kernel"]["huge"]
+    assert h["algorithmic_bytes_per_launch"] == 4_232_789 * 20 + 1024 * 1024 * 2 * 8
+    assert np.isclose(h["traffic"], 23.81) and h["traffic_over_algorithmic"] > 200
+    assert r["per_kernel"]["mid"]["traffic"] is None          # no PMC entry: null, never a guess
+    assert np.isclose(r["traffic"], 21.55)
+
+
+def test_reduce_selftest_pattern_sums_exactly_and_images_compare():
+    want = sum(bench.selftest_pattern(64, 2, r).astype(np.float64) for r in range(8))
+    acc = np.zeros((64, 64, 2), dtype=np.float32)
+    for r in range(8):
+        acc += bench.selftest_pattern(64, 2, r)
+    assert np.array_equal(acc.astype(np.float64), want)
+    whole = np.random.RandomState(0).uniform(0.0, 1.0, (64, 64, 2)).astype(np.float32)
+    whole[:8] = 0.0
+    ok = bench.compare_images(whole * np.float32(1.000001), whole, 8)
+    assert ok["ok"] and ok["max_rel"] < 1e-5 and ok["ranks"] == 8
+    bad = whole.copy(); bad[20, 20, 0] *= 1.001
+    assert not bench.compare_images(bad, whole, 8)["ok"]
+    dust = whole.copy(); dust[0, 0, 0] = 1e-30
+    assert not bench.compare_images(dust, whole, 8)["ok"]

@@ -66,17 +66,10 @@ def test_config1_1e7_weighted_against_the_oracle(native, mips):
     ctx.render(M, sf, mode=native.MODE_WEIGHTED)
     st = ctx.stats()
     got = ctx.read_image()
-    # ... and with the matrix-core kernel (an option since the end of round 4) drawing the footprints >= 384 px
-    ctx.set_option("p_mega2_px", 384)
-    ctx.render(M, sf, mode=native.MODE_WEIGHTED)
-    st3 = ctx.stats()
-    got3 = ctx.read_image()
     ctx.close()
     assert st["n_small"] + st["n_mid"] + st["n_huge"] + st["n_culled"] == n
     assert min(st["n_small"], st["n_mid"], st["n_huge"]) > 0 and st["n_mega"] == 0, "kernels S, M and H2 take part"
-    assert min(st3["n_huge"] - st3["n_mega"], st3["n_mega"]) > 0 and st3["n_fragments"] == st["n_fragments"], "... and H3 when asked to"
     assert st["n_fragments_stream"] + st["n_fragments_mid"] + st["n_fragments_huge"] + st["n_fragments_mega"] == st["n_fragments"]
-    assert st3["n_fragments_stream"] + st3["n_fragments_mid"] + st3["n_fragments_huge"] + st3["n_fragments_mega"] == st["n_fragments"]
     t = time.time()
     want, nfrag = oracle_c.splat(d["x"], d["y"], d["z"], d["h"], d["mass"], d["q"], mode=0, M=M, sf=float(sf), R=R, mips=mips)
     scale, _ = oracle_c.splat(d["x"], d["y"], d["z"], d["h"], d["mass"], np.abs(d["q"]), mode=0, M=M, sf=float(sf), R=R, mips=mips)
@@ -85,13 +78,11 @@ def test_config1_1e7_weighted_against_the_oracle(native, mips):
     assert max_rel(got[..., 0], want[..., 0]) <= 1e-5
     # the weighted channel cancels (signed q): within 1e-5 of the sum of |terms|
     assert (np.abs(got[..., 1].astype(np.float64) - want[..., 1]) <= 1e-5 * scale[..., 1].astype(np.float64) + 1e-30).all()
-    assert max_rel(got3[..., 0], want[..., 0]) <= 1e-5
-    assert (np.abs(got3[..., 1].astype(np.float64) - want[..., 1]) <= 1e-5 * scale[..., 1].astype(np.float64) + 1e-30).all()
 
 
 def test_sample_of_the_1e9_snapshot_against_the_oracle(native, mips):
     """The headline workload's own particles: the index range [0, 4e7) of the 1e9-particle snapshot (a uniform sample: the
-    generator's index bijection), density, 1024^2, camera A, through S + M + H2 (and, as the option, H3) against the oracle."""
+    generator's index bijection), density, 1024^2, camera A, through S + M + H2 against the oracle."""
     from oracle import oracle_c
     n_total, n, R = 10**9, 40_000_000, 1024
     M, sf = camera(200.0)
@@ -104,21 +95,15 @@ def test_sample_of_the_1e9_snapshot_against_the_oracle(native, mips):
     ctx.render(M, sf)
     st = ctx.stats()
     got = ctx.read_image()
-    ctx.set_option("p_mega_px", 768)           # the option: footprints >= 768 px on the matrix cores (the default of round 4)
-    ctx.render(M, sf)
-    st3 = ctx.stats()
-    got3 = ctx.read_image()
     ctx.close()
     assert st["n_small"] + st["n_mid"] + st["n_huge"] + st["n_culled"] == n
     assert min(st["n_small"], st["n_mid"], st["n_huge"]) > 0 and st["n_mega"] == 0
-    assert min(st3["n_huge"] - st3["n_mega"], st3["n_mega"]) > 0 and st3["n_fragments"] == st["n_fragments"]
     t = time.time()
     want, nfrag = oracle_c.splat(d["x"], d["y"], d["z"], d["h"], d["mass"], None, mode=0, M=M, sf=float(sf), R=R, mips=mips)
     print(f"oracle: {nfrag:.3g} fragments in {time.time() - t:.1f} s on {oracle_c.max_threads()} threads")
     assert st["n_fragments"] == nfrag, "coverage decisions differ from the oracle"
     assert max_rel(got[..., 0], want[..., 0]) <= 1e-5
-    assert max_rel(got3[..., 0], want[..., 0]) <= 1e-5
-    assert (got[..., 1] == 0).all() and (got3[..., 1] == 0).all()      # density render: q = 0 (particle_buffers.py:96-99)
+    assert (got[..., 1] == 0).all()      # density render: q = 0 (particle_buffers.py:96-99)
 
 
 def test_config4_mode_rgb_2048_against_the_oracle(native, mips):

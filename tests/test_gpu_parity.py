@@ -39,12 +39,6 @@ def check_2ch(got, want, abs_terms, rtol=1e-5):
     assert (d1 <= rtol * abs_terms + 1e-30).all(), "weighted channel beyond atol scaled by sum|terms|"
 
 
-def matrix_cores_on(ctx):
-    """Kernel H3 is an option since the end of round 4 (all three boundaries default to 0 = kernel H2 draws every footprint
-    >= 64 px): the boundaries of rounds 1-3 for the tests that cover it."""
-    ctx.set_option("p_mega_px", 512); ctx.set_option("p_mega2_px", 256); ctx.set_option("p_mega_rgb_px", 128)
-
-
 CAMERAS = [
     ("identity", np.eye(3), np.zeros(3), 200.0),
     ("zoom_rot", None, np.array([1.5, -2.0, 0.25]), 35.0),
@@ -59,7 +53,7 @@ def _rot(a, b):
     return rx @ ry
 
 
-@pytest.mark.parametrize("pipe", ["generic", "default", "matrix-cores"])
+@pytest.mark.parametrize("pipe", ["generic", "default"])
 @pytest.mark.parametrize("cam", CAMERAS, ids=[c[0] for c in CAMERAS])
 @pytest.mark.parametrize("R", [200, 1024])
 def test_weighted_matches_oracle(native, mips, cam, R, pipe):
@@ -73,8 +67,6 @@ def test_weighted_matches_oracle(native, mips, cam, R, pipe):
     ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
     ctx.upload_quantity(q)
     flags = native.PIPE_GENERIC if pipe == "generic" else native.PIPE_DEFAULT
-    if pipe == "matrix-cores":
-        matrix_cores_on(ctx)
     ctx.render(M, sf, mode=native.MODE_WEIGHTED, flags=flags)
     got = ctx.read_image()
     want, _ = oracle_render(pos, h, m, q, None, 0, M, sf, R, mips)
@@ -88,7 +80,7 @@ def test_weighted_matches_oracle(native, mips, cam, R, pipe):
     ctx.close()
 
 
-@pytest.mark.parametrize("pipe", ["generic", "default", "matrix-cores"])
+@pytest.mark.parametrize("pipe", ["generic", "default"])
 def test_rgb_and_depth_match_oracle(native, mips, pipe):
     from oracle import oracle_np
     R = 256
@@ -99,8 +91,6 @@ def test_rgb_and_depth_match_oracle(native, mips, pipe):
     ctx.set_kernel_mips(mips)
     ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, None)
     ctx.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
-    if pipe == "matrix-cores":
-        matrix_cores_on(ctx)
     ctx.render(M, sf, mode=native.MODE_RGB, flags=flags)
     got = ctx.read_image()
     want, _ = oracle_render(pos, h, rgb[:, 0].copy(), rgb[:, 1].copy(), rgb[:, 2].copy(), 2, M, sf, R, mips)
@@ -110,8 +100,6 @@ def test_rgb_and_depth_match_oracle(native, mips, pipe):
     ctx = native.Context(R, 2)
     ctx.set_kernel_mips(mips)
     ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
-    if pipe == "matrix-cores":
-        matrix_cores_on(ctx)
     ctx.render(M, sf, mode=native.MODE_DEPTH, flags=flags)
     got = ctx.read_image()
     want, _ = oracle_render(pos, h, m, None, None, 1, M, sf, R, mips)
@@ -446,31 +434,27 @@ def test_randomised_views(native, mips, seed):
         want, nfrag = oracle_render(pos, h, m, q, None, 0, M, sf, R, mips)
         check_2ch(ctx.read_image(), want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
     assert ctx.stats()["n_fragments"] == nfrag
-    # and once more with the exact disc culling active (no fragment statistics), then with the matrix-core kernel taking its share
+    # and once more with the exact disc culling active (no fragment statistics)
     ctx.set_option("count_fragments", 0)
     md = {"weighted": native.MODE_WEIGHTED, "rgb": native.MODE_RGB, "depth": native.MODE_DEPTH}[mode]
-    for matrix_cores in (False, True):
-        if matrix_cores:
-            matrix_cores_on(ctx)
-        ctx.render(M, sf, mode=md)
-        got = ctx.read_image()
-        if mode == "weighted":
-            check_2ch(got, want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
-        else:
-            assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=0)
-            if mode == "rgb":
-                assert np.array_equal(got[..., 3], want[..., 3])
+    ctx.render(M, sf, mode=md)
+    got = ctx.read_image()
+    if mode == "weighted":
+        check_2ch(got, want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
+    else:
+        assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=0)
+        if mode == "rgb":
+            assert np.array_equal(got[..., 3], want[..., 3])
     ctx.close()
 
 
 @pytest.mark.parametrize("mode", ["weighted", "depth", "rgb"])
 @pytest.mark.parametrize("R", [200, 1024])
 def test_gather_kernel_class_boundaries(native, mips, mode, R):
-    """Footprints right at the class boundaries of the tile-gather kernels -- 64 px (nearest mip 0 -> bilinear: kernel M
-    -> H2; a texel row per pixel row, the one case where rounding may skip a texel row) and p_mega (H2 / H -> H3 on the
-    matrix cores: 768 px for density, 384 px for the two-channel modes, 128 px for rgb) -- at arbitrary sub-pixel centres,
-    partly off-screen, against the oracle: image within 1e-5 and the exact fragment count.  R = 200 leaves partial tiles
-    and strips on both axes."""
+    """Footprints right at the class boundary of the tile-gather kernel -- 64 px (nearest mip 0 -> bilinear: kernel M -> H2; a
+    texel row per pixel row, the one case where rounding may skip a texel row) -- and at the widths where rounds 1-4 switched
+    kernels (128 / 256 / 384 / 512 / 768 px), at arbitrary sub-pixel centres, partly off-screen, against the oracle: image
+    within 1e-5 and the exact fragment count.  R = 200 leaves partial tiles and strips on both axes."""
     from oracle import oracle_np
     scale = 100.0
     M, sf = oracle_np.transform_matrix(_rot(0.0, 0.0), np.zeros(3), scale)
@@ -493,8 +477,6 @@ def test_gather_kernel_class_boundaries(native, mips, mode, R):
     ctx = native.Context(R, 4 if mode == "rgb" else 2)
     ctx.set_kernel_mips(mips)
     ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, None if mode == "rgb" else m)
-    # kernel H2 draws everything >= 64 px by default (rgb: round 4; density, two-channel: end of round 4): H3 from 128 / 384 px here
-    ctx.set_option("p_mega_rgb_px", 128); ctx.set_option("p_mega2_px", 384)
     for count in (1, 0):                       # with fragment statistics (no disc culling), then with the exact culling
         ctx.set_option("count_fragments", count)
         if mode == "rgb":
@@ -516,35 +498,31 @@ def test_gather_kernel_class_boundaries(native, mips, mode, R):
         st = ctx.stats()
         if count:
             assert st["n_fragments"] == nfrag
-        p_mega = 128.0 if mode == "rgb" else 384.0          # (weighted with a quantity and depth are two-channel renders)
-        wide = int((h.astype(np.float64) * 2.0 * R / scale >= p_mega).sum())
-        assert 0 < st["n_mega"] <= wide             # (some of them are off-screen or outside the z-slab)
-        assert st["n_mega"] > wide // 3
-    # the kernel variants that large record counts (or options) select, same scene, exact culling on
-    extra = {"rgb": [("rgb_mega_variant", 1), ("rgb_mega_variant", 3), ("rgb_mega_variant", 4), ("huge_variant", 0), ("p_mega_rgb_px", 0)],
-             "weighted": [("mega_variant", 4), ("mega_variant", 3), ("mega_variant", 5), ("huge_variant", 4), ("p_mega2_px", 0)],
-             "depth": [("mega_variant", 4), ("mega_variant", 5), ("p_mega2_px", 0)]}[mode]
-    for name, value in extra:
-        ctx.set_option(name, value)
+        assert st["n_mega"] == 0                    # (kernel I is an option: nothing leaves the huge list by default)
+        wide = int((h.astype(np.float64) * 2.0 * R / scale >= 64.0).sum())
+        assert wide // 3 < st["n_huge"] <= wide     # (some of them are off-screen or outside the z-slab)
+    # kernel H2's other strip shape / occupancy builds (what other record counts select, and the A/B builds), exact culling on
+    for variant in {"rgb": (4,), "weighted": (4,), "depth": (4,)}[mode]:
+        ctx.set_option("huge_variant", variant)
         if mode == "rgb":
             ctx.render(M, sf, mode=native.MODE_RGB)
             got = ctx.read_image()
-            assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=0), (name, value)
-            assert np.array_equal(got[..., 3], want[..., 3]), (name, value)
+            assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=0), variant
+            assert np.array_equal(got[..., 3], want[..., 3]), variant
         elif mode == "depth":
             ctx.render(M, sf, mode=native.MODE_DEPTH)
-            assert np.allclose(ctx.read_image(), want, rtol=1e-5, atol=0), (name, value)
+            assert np.allclose(ctx.read_image(), want, rtol=1e-5, atol=0), variant
         else:
             ctx.render(M, sf, mode=native.MODE_WEIGHTED)
             check_2ch(ctx.read_image(), want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
-        ctx.set_option(name, {"rgb_mega_variant": 2, "mega_variant": 0, "huge_variant": 1, "p_mega_rgb_px": 128, "p_mega2_px": 384}[name])
+        ctx.set_option("huge_variant", 1)
     ctx.close()
 
 
 def test_gather_kernels_fold_their_accumulators(native, mips):
-    """More than 512 footprints per wave strip: kernels H2 and H3 flush their float32 accumulators to the float64 target
-    every 512 footprints (forced here by one workgroup per tile); density stays within 1e-5 of the oracle, and the class
-    split (H2 alone against H2 + H3) does not change the image beyond the summation order."""
+    """More than 512 footprints per wave strip: kernel H2 flushes its float32 accumulators to the float64 target every 512
+    footprints (forced here by one workgroup per tile); density stays within 1e-5 of the oracle for every strip shape /
+    occupancy build, the exact fragment count included, and the workgroup order (XCD-aware or tile-major) changes nothing."""
     from oracle import oracle_np
     R, scale, n = 160, 100.0, 2600
     M, sf = oracle_np.transform_matrix(np.eye(3), np.zeros(3), scale)
@@ -558,47 +536,24 @@ def test_gather_kernels_fold_their_accumulators(native, mips):
     ctx.set_kernel_mips(mips)
     ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
     ctx.set_option("huge_split", 1)
-    ctx.set_option("mega_split", 1)
-    ctx.set_option("p_mega_px", 512)           # the class split this scene was laid out for (kernel H3 is an option since the end of round 4)
     ctx.render(M, sf)
     got = ctx.read_image()
-    assert ctx.stats()["n_mega"] == n // 2 and ctx.stats()["n_huge"] == n
-    want, _ = oracle_render(pos, h, m, None, None, 0, M, sf, R, mips)
+    assert ctx.stats()["n_mega"] == 0 and ctx.stats()["n_huge"] == n
+    want, nfrag = oracle_render(pos, h, m, None, None, 0, M, sf, R, mips)
     assert np.allclose(got[..., 0], want[..., 0], rtol=1e-5, atol=0)
-    for variant in (1, 2, 3):                  # kernel H3 on 64 x 32 strips, on 64 x 64 strips at 4 / 3 waves per SIMD
-        ctx.set_option("mega_variant", variant)
-        ctx.render(M, sf)
-        assert ctx.stats()["n_mega"] == n // 2
-        assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0), variant
-    ctx.set_option("mega_variant", 0)
-    ctx.set_option("p_mega_px", 0)             # everything >= 64 px through kernel H2
-    ctx.render(M, sf)
-    assert ctx.stats()["n_mega"] == 0
-    assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0)
-    # H2's strip shapes / occupancies: 64x32 strips at 4 and 6 waves per SIMD (7 = what large record counts select since
-    # round 4, row factors fetched group by group), 64x16 at 7 / 8 / 6
+    # H2's strip shapes / occupancies: 64x32 strips at 6 / 8 / 7 waves per SIMD (7 = what large record counts select,
+    # row factors fetched group by group), 64x16 at 7 / 8
     for variant in (2, 7, 4, 5, 6):
         ctx.set_option("huge_variant", variant)
         ctx.render(M, sf)
         assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0), variant
-    ctx.set_option("p_mega_px", 512)
-    ctx.set_option("huge_variant", 7)
-    for variant in (1, 2, 4):                  # ... combined with H3 on 64x32 strips at 4 / 5 waves and on 64x64 strips
-        ctx.set_option("mega_variant", variant)
-        ctx.render(M, sf)
-        assert ctx.stats()["n_mega"] == n // 2
-        assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0), variant
-    ctx.set_option("mega_variant", 0)
-    ctx.set_option("p_mega_px", 0)
-    ctx.set_option("huge_variant", 0)          # and through the round-1 kernel H
-    ctx.render(M, sf)
-    assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0)
-    ctx.set_option("huge_variant", 3)          # and through kernel H4 (v_mfma_f32_16x16x4_f32 on 64 x 16 strips; experimental)
+    ctx.set_option("huge_variant", 1)
     ctx.set_option("count_fragments", 1)
-    ctx.render(M, sf)
-    assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0)
-    _, nfrag = oracle_render(pos, h, m, None, None, 0, M, sf, R, mips)
-    assert ctx.stats()["n_fragments"] == nfrag
+    for split, group in ((8, 16), (8, 0), (16, 3), (24, 1)):      # several workgroups per tile, both workgroup orders, odd group sizes
+        ctx.set_option("huge_split", split); ctx.set_option("mid_split", split); ctx.set_option("xcd_group", group)
+        ctx.render(M, sf)
+        assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0), (split, group)
+        assert ctx.stats()["n_fragments"] == nfrag, (split, group)
     ctx.close()
 
 

@@ -344,15 +344,14 @@ def test_rgb_2048_matches_oracle_at_class_boundaries(native, mips):
     ctx.close()
 
 
-@pytest.mark.parametrize("label,h_values", [("all-mega", (60.0,)), ("huge+mega", (20.0, 60.0))])
-def test_record_list_overflow_replay_with_mega_records(native, mips, label, h_values):
-    """The huge list holds H2's records from the front and H3's 'mega' records (P >= 512 px) from the back; an overflow
-    of the sum replays kernel S after growing the list.  n > 16 * 65536 so the first frame must overflow, grow and
-    replay with mega records taking part; weighted (NW = 1) and rgb (NW = 2 weights per record)."""
+@pytest.mark.parametrize("label,h_values", [("wide", (60.0,)), ("two-widths", (20.0, 60.0))])
+def test_record_list_overflow_replay(native, mips, label, h_values):
+    """An overflow of the huge-record list replays kernel S (records only) after growing the list.  n > 16 * 65536 so the
+    first frame must overflow, grow and replay; weighted (NW = 1) and rgb (NW = 2 weights per record)."""
     n, R = 1_100_000, 1024
     rs = np.random.RandomState(8)
     pos = (rs.normal(size=(n, 3)) * 60.0).astype(np.float32)
-    h = rs.choice(np.asarray(h_values, dtype=np.float32), size=n)          # P = 2 h R / scale = 204.8 px (H2; rgb: H3) or 614.4 px (H3)
+    h = rs.choice(np.asarray(h_values, dtype=np.float32), size=n)          # P = 2 h R / scale = 204.8 px or 614.4 px: all kernel H2's
     m = rs.uniform(0.5, 1.5, n).astype(np.float32)
     rgb = rs.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32)
     M, sf = camera(200.0)
@@ -361,17 +360,11 @@ def test_record_list_overflow_replay_with_mega_records(native, mips, label, h_va
         c2.set_kernel_mips(mips)
         c2.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
         c2.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
-        c2.set_option("p_mega_px", 512)          # (the default moved to 768 px in round 4; 614-px footprints must stay mega records here)
-        c2.set_option("p_mega_rgb_px", 128)      # (rgb: no H3 by default since round 4)
         c2.render(M, sf, mode=mode)              # first frame: overflow -> grow -> replay
         st = c2.stats()
         a = c2.read_image().astype(np.float64)
         assert st["n_huge"] > 16 * 65536 and st["n_small"] == 0 and st["n_mid"] == 0
-        assert st["n_mega"] > 0
-        if mode == native.MODE_RGB:              # rgb: kernel H3 from 128 px, so both widths are mega records
-            assert st["n_mega"] == st["n_huge"]
-        else:                                    # density: from p_mega_px = 512 px here
-            assert (st["n_mega"] == st["n_huge"]) == (label == "all-mega")
+        assert st["n_mega"] == 0                 # (the tail of the list belongs to the option integrated_px)
         assert st["n_huge"] + st["n_culled"] == n
         c2.render(M, sf, mode=mode)              # second frame: the lists are large enough now
         b = c2.read_image().astype(np.float64)
@@ -383,3 +376,71 @@ def test_record_list_overflow_replay_with_mega_records(native, mips, label, h_va
         if mode == native.MODE_RGB:
             assert np.array_equal(a[..., 3], g[..., 3]) and np.array_equal(b[..., 3], g[..., 3])
         c2.close()
+
+
+def test_reorder_interleave_keeps_cells_and_images(native, mips):
+    """tsp_reorder_spatial transposes every 512-particle block of the Morton order 64 x 8 (lane decorrelation for kernel S,
+    option reorder_interleave, on by default).  The permutation stays a bijection, every (stratum, cell) run keeps exactly its
+    own particles (view culling by cell runs), and the render -- image and exact fragment count -- does not depend on it."""
+    n, R = 300_000, 512
+    M, sf = camera(200.0)
+    out = {}
+    for inter in (1, 0):
+        ctx = native.Context(R, 2)
+        ctx.set_kernel_mips(mips)
+        ctx.set_option("reorder_interleave", inter)
+        ctx.generate_synthetic(n, 0, n, 1337, 0.0)
+        perm = ctx.reorder_spatial(8, 1337, want_permutation=True)
+        assert np.array_equal(np.sort(perm), np.arange(n))
+        ctx.set_option("count_fragments", 1)
+        ctx.render(M, sf)
+        out[inter] = (perm, ctx.cell_layout()["offsets"], ctx.strata_offsets(), ctx.read_image().astype(np.float64), ctx.stats()["n_fragments"])
+        ctx.close()
+    (p1, c1, s1, img1, f1), (p0, c0, s0, img0, f0) = out[1], out[0]
+    assert np.array_equal(c1, c0) and np.array_equal(s1, s0)
+    assert not np.array_equal(p1, p0), "the interleave changed nothing"
+    for a, b in zip(c1[:-1][::37], c1[1:][::37]):          # a sample of the cell runs: the same particles, in another order
+        assert np.array_equal(np.sort(p1[a:b]), np.sort(p0[a:b]))
+    # inside one aligned block that lies in one cell: slot (r mod 8) * 64 + r / 8 holds Morton rank r
+    sizes = np.diff(c1)
+    big = int(np.argmax(sizes))
+    b0 = -(-int(c1[big]) // 512) * 512
+    assert b0 + 512 <= c1[big + 1]
+    r = np.arange(512)
+    assert np.array_equal(p1[b0 + (r % 8) * 64 + r // 8], p0[b0 + r])
+    assert f1 == f0
+    assert rel_close(img1[..., 0], img0[..., 0], 1e-5)
+
+
+def test_vertex_weights_follow_every_upload(native, mips):
+    """Kernel S streams m / h^2 (rgb / h^2) formed once per upload: a new mass, smoothing-length or rgb array must reach the
+    next frame (the generic kernel divides per fragment and serves as the reference here)."""
+    n, R = 50_000, 256
+    rs = np.random.RandomState(3)
+    pos = (rs.normal(size=(n, 3)) * 40.0).astype(np.float32)
+    M, sf = camera(200.0)
+    ctx = native.Context(R, 4)
+    ctx.set_kernel_mips(mips)
+
+    def check(mode):
+        ctx.render(M, sf, mode=mode)
+        a = ctx.read_image().astype(np.float64)
+        ctx.render(M, sf, mode=mode, flags=native.PIPE_GENERIC)
+        g = ctx.read_image().astype(np.float64)
+        for c in range(3 if mode == native.MODE_RGB else 1):
+            assert g[..., c].sum() > 0 and rel_close(a[..., c], g[..., c], 1e-5)
+
+    for trial in range(3):
+        h = rs.uniform(0.2, 6.0, n).astype(np.float32)
+        m = rs.uniform(0.5, 1.5, n).astype(np.float32) * (10.0 ** trial)
+        ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+        check(native.MODE_WEIGHTED)
+        for rgb_trial in range(2):
+            rgb = rs.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32) * (3.0 ** rgb_trial)
+            ctx.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
+            check(native.MODE_RGB)
+        if trial == 1:
+            ctx.reorder_spatial(4, 7)
+            check(native.MODE_WEIGHTED)
+            check(native.MODE_RGB)
+    ctx.close()

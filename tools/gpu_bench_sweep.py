@@ -7,11 +7,12 @@ from topsy_amd import kernel_lut, _native
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20000000
 opts = dict(kv.split("=") for kv in sys.argv[2:])
 R = int(opts.pop("R", 1024)); scale = float(opts.pop("scale", 200.0)); hcap_px = float(opts.pop("hcap", 0))
-ntotal = int(float(opts.pop("ntotal", n)))
+ntotal = int(float(opts.pop("ntotal", n))); first = int(float(opts.pop("first", 0)))
 reorder = int(opts.pop("reorder", 32)); frames = int(opts.pop("frames", 5)); mode = opts.pop("mode", "density")
 ctx = _native.Context(R, 4 if mode == "rgb" else 2); ctx.set_kernel_mips(kernel_lut.kernel_mips())
+for k, v in opts.items(): ctx.set_option(k, int(v))     # (load-time options such as reorder_interleave are read by reorder_spatial)
 t = time.time()
-ctx.generate_synthetic(ntotal, 0, n, 1337, hcap_px * scale / (2.0 * R), with_quantity=(mode == "weighted"), with_rgb=(mode == "rgb"))
+ctx.generate_synthetic(ntotal, first, n, 1337, hcap_px * scale / (2.0 * R), with_quantity=(mode == "weighted"), with_rgb=(mode == "rgb"))
 tg = time.time() - t; t = time.time()
 if reorder: ctx.reorder_spatial(reorder, 1337)
 print(f"n={n:.3g} generate {tg:.2f}s reorder {time.time()-t:.2f}s")

@@ -8,7 +8,13 @@ TARGET_FPS = 30                      # config.py:6
 INITIAL_PARTICLES_TO_RENDER = 1e5    # config.py:7
 COLORMAP_NUM_SAMPLES = 1000          # config.py:14
 TEST_DATA_NUM_PARTICLES_DEFAULT = int(1e6)   # config.py:16
-MAX_PARTICLES_PER_EXPORT_RENDERCALL = 2 ** 25  # config.py:22
+# The reference cuts an EXPORT frame into submissions of 2^25 particles (config.py:22-25: "pipeline stalls" of a WebGPU render
+# pass above that size).  A HIP launch has no such limit -- the 1e9-particle snapshot renders in ONE tsp_render call -- and every
+# extra block costs the tile kernels' per-launch start-up again (30 blocks: ~3x the frame time at 1e9), so this backend's cap
+# is "never" (tsp_render itself takes < 2^32 particles per context).  The reference's value stays selectable:
+# tests replay the reference's golden block sequences with it (tests/test_host_logic.py).
+REFERENCE_MAX_PARTICLES_PER_EXPORT_RENDERCALL = 2 ** 25   # config.py:22
+MAX_PARTICLES_PER_EXPORT_RENDERCALL = 2 ** 40
 DEFAULT_CELLS_NSIDE = 16             # config.py:27
 CELL_LAYOUT_FRACTIONAL_PADDING = 1e-5  # config.py:33
 

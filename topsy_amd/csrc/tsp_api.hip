@@ -82,6 +82,12 @@ static void free_particles(tsp_context *ctx) {
         if (*a) (void)hipFree(*a);
         *a = nullptr;
     }
+    float **derived[] = {&p.wm, &p.wr, &p.wg, &p.wb};
+    for (float **a : derived) {
+        if (*a) (void)hipFree(*a);
+        *a = nullptr;
+    }
+    p.wm_valid = p.wrgb_valid = false;
     if (p.perm) (void)hipFree(p.perm);
     p.perm = nullptr;
     p.n = 0;
@@ -98,7 +104,7 @@ using namespace tsp;
 extern "C" {
 
 const char *tsp_last_error(void) { return g_err; }
-int tsp_version(void) { return 103; }     // 101: tsp_stats gained ms_mega, n_mega (16 bytes); 102: the per-kernel fragment counts (32 bytes); 103: n_chunk_culled (8 bytes)
+int tsp_version(void) { return 104; }     // 101: tsp_stats gained ms_mega, n_mega (16 bytes); 102: the per-kernel fragment counts (32 bytes); 103: n_chunk_culled (8 bytes); 104: matrix-core options removed
 int tsp_stats_size(void) { return (int)sizeof(tsp_stats); }
 
 int tsp_device_count(void) {
@@ -260,6 +266,7 @@ int tsp_upload_rgb(tsp_context *ctx, const float *r, const float *g, const float
     if ((rc = upload_permuted(ctx, &ctx->p.r, r, ctx->p.n))) return rc;
     if ((rc = upload_permuted(ctx, &ctx->p.g, g, ctx->p.n))) return rc;
     if ((rc = upload_permuted(ctx, &ctx->p.b, b, ctx->p.n))) return rc;
+    ctx->p.wrgb_valid = false;
     TSP_HIP(hipStreamSynchronize(ctx->stream));
     return TSP_OK;
 }
@@ -301,6 +308,7 @@ int tsp_upload_band_magnitudes(tsp_context *ctx, int n_bands, const double *mags
     const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)ctx->cu_count * 16);
     hipLaunchKernelGGL(band_contraction_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_mags.as<double>(), d_w.as<double>(), n_bands, n,
                        ctx->p.perm, ctx->p.r, ctx->p.g, ctx->p.b);
+    ctx->p.wrgb_valid = false;
     TSP_HIP(hipGetLastError());
     TSP_HIP(hipStreamSynchronize(ctx->stream));
     return TSP_OK;
@@ -696,7 +704,7 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         ctx->debug_extra_lds = (int)value;
         return TSP_OK;
     }
-    if (!strcmp(name, "mega_split")) {
+    if (!strcmp(name, "mega_split")) {        // workgroups per tile of kernel I
         TSP_REQUIRE(value >= 0 && value <= 4096, TSP_EINVAL, "%s out of range", name);
         ctx->mega_split = (int)value;
         return TSP_OK;
@@ -706,12 +714,6 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         if (name[0] == 'm') ctx->mid_split = value > 0 ? (int)value : 1;
         else if (name[0] == 'h') ctx->huge_split = (int)value;
         else ctx->stream_blocks_per_cu = value > 0 ? (int)value : 1;
-        return TSP_OK;
-    }
-    if (!strcmp(name, "p_mega_px") || !strcmp(name, "p_mega2_px") || !strcmp(name, "p_mega_rgb_px")) {
-        // class boundary H2 (rgb: H) / H3 in pixels (>= 64; 0 = no H3) for density / two-channel / rgb renders
-        TSP_REQUIRE(value == 0 || (value >= 64 && value <= (1 << 20)), TSP_EINVAL, "%s out of range", name);
-        (name[6] == '2' ? ctx->p_mega2 : (name[6] == '_' && name[7] == 'r' ? ctx->p_mega_rgb : ctx->p_mega)) = (float)value;
         return TSP_OK;
     }
     if (!strcmp(name, "integrated_px")) {     // density footprints at least this wide go through kernel I (0 = off, else >= 128: below that the
@@ -724,19 +726,24 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         }
         return TSP_OK;
     }
-    if (!strcmp(name, "mega_variant")) {
-        TSP_REQUIRE(value >= 0 && value <= 5, TSP_EINVAL, "mega_variant out of range");
-        ctx->mega_variant = (int)value;
-        return TSP_OK;
-    }
-    if (!strcmp(name, "rgb_mega_variant")) {
-        TSP_REQUIRE(value >= 0 && value <= 4, TSP_EINVAL, "rgb_mega_variant out of range");
-        ctx->rgb_mega_variant = (int)value;
-        return TSP_OK;
-    }
     if (!strcmp(name, "huge_variant")) {
-        TSP_REQUIRE(value >= 0 && value <= 7, TSP_EINVAL, "huge_variant out of range");
+        // 1 = auto; 2, 4-7 force a strip shape / occupancy of kernel H2 (A/B and tests)
+        TSP_REQUIRE(value >= 1 && value <= 7 && value != 3, TSP_EINVAL, "huge_variant out of range");
         ctx->huge_variant = (int)value;
+        return TSP_OK;
+    }
+    if (!strcmp(name, "xcd_group_mid")) {
+        TSP_REQUIRE(value >= -1 && value <= 4096, TSP_EINVAL, "%s out of range", name);
+        ctx->xcd_group_mid = (int)value;
+        return TSP_OK;
+    }
+    if (!strcmp(name, "xcd_group")) {         // tiles per slice in the XCD-aware workgroup order of kernels M / H2 (0 = tile-major, as rounds 1-4)
+        TSP_REQUIRE(value >= 0 && value <= 4096, TSP_EINVAL, "%s out of range", name);
+        ctx->xcd_group = (int)value;
+        return TSP_OK;
+    }
+    if (!strcmp(name, "reorder_interleave")) {   // read by the next tsp_reorder_spatial
+        ctx->reorder_interleave = value != 0;
         return TSP_OK;
     }
     if (!strcmp(name, "chunk_cull")) {        // 1 (default): kernel S skips the chunks whose bounds lie outside the view

@@ -250,10 +250,64 @@ __global__ void key_prefix_offsets_kernel(const uint64_t *__restrict__ keys, int
     offsets[e] = lo;
 }
 
+// ------------------------------------------------------------------------------------------------
+// vertex weights, once per upload
+// ------------------------------------------------------------------------------------------------
+// vertex_weighting / vertex_rgb (sph.wgsl:69-83) divide the mass (the three band masses) by h*h for every vertex of every
+// frame; the quotient does not depend on the camera.  Same float32 operations (one multiply, one IEEE division), once.
+__global__ __launch_bounds__(256) void weights_kernel(const float *__restrict__ h, const float *__restrict__ a, const float *__restrict__ b,
+                                                      const float *__restrict__ c, int64_t n, float *__restrict__ wa,
+                                                      float *__restrict__ wb, float *__restrict__ wc) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float hh = h[i] * h[i];
+        wa[i] = a[i] / hh;
+        if (b) { wb[i] = b[i] / hh; wc[i] = c[i] / hh; }
+    }
+}
+
+int ensure_weights(tsp_context *ctx, bool rgb) {
+    Particles &p = ctx->p;
+    if (p.n == 0 || (rgb ? p.wrgb_valid : p.wm_valid)) return TSP_OK;
+    int rc;
+    const unsigned grid = (unsigned)std::min<int64_t>((p.n + 255) / 256, (int64_t)ctx->cu_count * 32);
+    if (rgb) {
+        if ((rc = ensure_array(&p.wr, p.n)) || (rc = ensure_array(&p.wg, p.n)) || (rc = ensure_array(&p.wb, p.n))) return rc;
+        hipLaunchKernelGGL(weights_kernel, dim3(grid), dim3(256), 0, ctx->stream, p.h, p.r, p.g, p.b, p.n, p.wr, p.wg, p.wb);
+        p.wrgb_valid = true;
+    } else {
+        if ((rc = ensure_array(&p.wm, p.n))) return rc;
+        hipLaunchKernelGGL(weights_kernel, dim3(grid), dim3(256), 0, ctx->stream, p.h, p.m, (const float *)nullptr, (const float *)nullptr, p.n,
+                           p.wm, (float *)nullptr, (float *)nullptr);
+        p.wm_valid = true;
+    }
+    TSP_HIP(hipGetLastError());
+    return TSP_OK;
+}
+
+// order_out[a + t(r, L)] = order_in[a + r] for every segment [a, a + L) = (aligned 512-block) x (cell run): t transposes the
+// segment's ranks 8-way, r -> (r mod 8) * ceil-ish(L / 8) + r / 8 (rows r mod 8 < L mod 8 hold one element more): a bijection
+__global__ __launch_bounds__(256) void interleave_order_kernel(const uint32_t *__restrict__ order_in, uint32_t *__restrict__ order_out,
+                                                               const uint64_t *__restrict__ sorted_keys, const int64_t *__restrict__ cell_start,
+                                                               int shift, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t cell = (int64_t)(sorted_keys[i] >> shift);
+        const int64_t b0 = i & ~(int64_t)(BOUNDS_BLOCK - 1);
+        const int64_t a = max(b0, cell_start[cell]), e = min(min(b0 + BOUNDS_BLOCK, n), cell_start[cell + 1]);
+        const int64_t L = e - a, r = i - a;
+        int64_t j = i;
+        if (L >= 16 && r >= 0 && r < L) {
+            const int64_t q = L >> 3, rem = L & 7, row = r & 7;
+            j = a + row * q + min(row, rem) + (r >> 3);
+        }
+        order_out[j] = order_in[i];
+    }
+}
+
 int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out) {
     Particles &p = ctx->p;
     const int64_t n = p.n;
     ctx->ws.bounds_valid = false;
+    p.wm_valid = p.wrgb_valid = false;       // (recomputed in the new order by the next render)
     hipStream_t st = ctx->stream;
     float lo[3], inv[3];
     {   // bounding box of the positions
@@ -316,6 +370,19 @@ int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm
             ctx->cell_lo[a] = lo[a];
             // a cell spans 2^(16 - k) quantisation steps of 1 / inv world units each (inv = 0: a degenerate axis, one cell)
             ctx->cell_width[a] = inv[a] > 0.0f ? (float)(1 << (16 - k)) / inv[a] : 0.0f;
+        }
+        // Lane decorrelation (round 5): kernel S gives one lane per particle and 64 consecutive particles per wave step.  Morton
+        // neighbours are neighbours on screen, so the lanes of a step scatter their footprints into the same few pixels of the LDS
+        // window -- same-address ds_add_f64 (a quarter of the LDS pipe's busy cycles at 1e9 particles).  Inside every aligned
+        // block of 512 particles (kernel S's chunk) the Morton order is therefore transposed 64 x 8 -> 8 x 64: a wave step
+        // then holds every eighth particle of the block -- twice the spread on screen per axis -- while the block, its bounding
+        // box and its window stay what they were.  Blocks are cut at cell boundaries, so every (stratum, cell) run keeps
+        // exactly its own particles (view culling by cell runs is unaffected).
+        if (ctx->reorder_interleave) {
+            hipLaunchKernelGGL(interleave_order_kernel, dim3(4096), dim3(256), 0, st, order.as<uint32_t>(), vals.as<uint32_t>(), keys2.as<uint64_t>(),
+                               d_cell.as<int64_t>(), 48 - 3 * k, n);
+            TSP_HIP(hipGetLastError());
+            void *t = order.p; order.p = vals.p; vals.p = t;
         }
         TSP_HIP(hipStreamSynchronize(st));
     }

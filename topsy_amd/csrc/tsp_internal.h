@@ -39,6 +39,12 @@ struct Particles {
     float *q = nullptr;                      // nullptr -> density render (q = 0)
     float *r = nullptr, *g = nullptr, *b = nullptr;
     uint32_t *perm = nullptr;                // new -> old index after tsp_reorder_spatial (else nullptr)
+    // camera-independent vertex weights (sph.wgsl:76-83 `mass / (h*h)`, :69-73 `rgb / (h*h)`), formed once per upload by
+    // ensure_weights() with the float32 operations the shader performs per vertex and frame: what kernel S streams
+    // instead of m (r, g, b) -- the same bytes per particle, no division per particle and frame
+    float *wm = nullptr;
+    float *wr = nullptr, *wg = nullptr, *wb = nullptr;
+    bool wm_valid = false, wrgb_valid = false;   // cleared whenever h / m / rgb change (upload, generate, reorder)
 };
 
 // Bounds of every block of BOUNDS_BLOCK consecutive particles (view culling of whole chunks, kernel S): two float4 per block,
@@ -55,7 +61,7 @@ struct Record4 {   // rgb variant (24 B)
 
 struct Counters {      // device-side, zeroed per render call
     unsigned long long n_small, n_mid, n_huge, n_culled, n_fragments, huge_count, n_mega, pad1;
-    unsigned long long n_frag_class[4];   // n_fragments by the kernel that drew them: S, M, H / H2, H3 / I
+    unsigned long long n_frag_class[4];   // n_fragments by the kernel that drew them: S, M, H2, I
 };
 
 struct Workspace {     // per-context scratch of the three-class pipeline (grown on demand)
@@ -93,7 +99,7 @@ struct tsp_context {
     int R = 0, C = 0, Ccap = 0;       // C = active channels (2 or 4) <= Ccap
     bool use_quantity = true;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;    // kernel M runs here, concurrently with kernel H on `stream`
+    hipStream_t stream2 = nullptr;    // option overlap_mid_huge: kernel M runs here, concurrently with kernel H2 on `stream`
     hipEvent_t ev[12] = {};
     float *image = nullptr;           // R*R*C float32 render target (what read-back, colormap and reduce see)
     double *image64 = nullptr;        // float64 master copy every kernel accumulates into (rounded once per render)
@@ -126,22 +132,15 @@ struct tsp_context {
     bool count_fragments = false;
     // pipeline tuning (tsp_set_option)
     float p_small = 16.0f;             // footprints narrower than this many pixels are splatted by kernel S (mips 3 and 2; <= 16: its texel columns are packed 16 x 4 bits)
-    float p_mega = 0.0f;              // density renders: footprints at least this wide go to kernel H3 (matrix cores); 0 = all to H2, the default since the
-                                      // end of round 4.  f32 MFMA and packed-f32 VALU have the SAME peak on gfx950 (256 flop/clk/CU); the GEMM form issues 2 K flop per
-                                      // pixel (K = texel rows under 32 pixel rows, padded to >= 2, typically 4) where H2 issues 4, so once H2 had lost its spills
-                                      // H3 only wins from ~1536 px up (measured: H3 off, 1e7 7.07 -> 6.2 ms, 1e8 19.6 -> 18.1, 1.25e8 21.4 -> 20.5, 1e9 68.1 -> 66.7;
-                                      // only a 10x zoom at 1e8 -- every record wider than the image -- is 4 % faster with it).  History: 512 px (round 3), 768 (round 4)
-    float p_mega2 = 0.0f;             // the same for two-channel renders (weighted, depth); 0 since the end of round 4 too (H3 off: 1e7 weighted 9.03 -> 8.68 ms,
-                                      // 1e8 28.7 -> 27.7, 5e8 71.5 -> 69.2; before: 256 px, then 384)
-    float p_mega_rgb = 0.0f;          // ... and for rgb: 0 = no H3 at all since round 4 -- kernel H2 with three accumulator sets draws every footprint >= 64 px (config 4: 77.9 ms against 85.0 with H3 from 128 px, 82.7 / 80.3 from 384 / 768 px; 5e6 particles at 1024^2: 14.9 against 18.3 ms)
     float integrated_px = 0.0f;       // option: density footprints at least this wide (>= 128) go through kernel I (second differences + prefix sums, tsp_integrated.hip); 0 = off
     float int_peak = 0.0f;            // kernel I: largest level-0 texel
     unsigned long long int_edge[2] = {0, 0};   // kernel I: rows of S0 with a non-zero edge jump (bit q of 66)
     double *int_tables = nullptr;     // kernel I: breakpoint strengths of the level-0 kernel image and their prefix sums (integrated_tables)
-    int mega_variant = 0;             // density: 0 = auto, 1 = kernel H3 on 64 x 32 strips, 2 / 3 = on 64 x 64 strips at 4 / 3 waves per SIMD
-    int rgb_mega_variant = 2;         // rgb: 0 = every footprint >= 64 px on kernel H / H2; 1-4: those >= p_mega on kernel H3 with three accumulator sets (2: 64x32 strips at 3 waves/SIMD, 50.9 ms against 53.5 for 32x32 strips at config 4)
-    int huge_variant = 1;             // 0: kernel H (per-pixel gather, A/B only), 1: kernels H2 (64x16 strips) + H3, 2: H2 with 64x32 strips (density)
-    int mid_split = 128, huge_split = 0, mega_split = 0;  // workgroups per image tile (0 = auto)
+    int huge_variant = 1;             // kernel H2's strip shape / occupancy: 1 = auto (density: 64x32 strips at 8 waves/SIMD from 7e5 records, 64x16 below; two channels 64x16 at 7; rgb at 5), 2 / 4-7 = A/B builds
+    int mid_split = 128, huge_split = 0, mega_split = 0;  // workgroups per image tile of kernels M / H2 / I (0 = auto)
+    int xcd_group_mid = -1;          // kernel M's own value of xcd_group (-1: follow xcd_group)
+    int xcd_group = 16;              // tile kernels: tiles an XCD walks per slice of the record list (tile_and_split(), tsp_pipeline.h); 0 = the tile-major order of rounds 1-4
+    bool reorder_interleave = true;  // tsp_reorder_spatial transposes every 512-particle block 64 x 8 (lane decorrelation for kernel S, tsp_data.hip)
     int stream_blocks_per_cu = 100;  // kernel S grid bound: ~10 chunks per workgroup at 1e8 particles balances dense and sparse chunks
     bool chunk_cull = true;           // chunks (512 consecutive particles) whose bounds lie outside the view are skipped by kernel S
                                       // unread: pays with a load-time spatial order (tsp_reorder_spatial); identical results
@@ -184,6 +183,7 @@ int launch_colormap_bivariate(tsp_context *ctx, const float *d_img, int64_t npix
 int generate_synthetic(tsp_context *ctx, int64_t n_total, int64_t first, int64_t count, uint64_t seed,
                        float h_cap, int with_quantity, int with_rgb);
 int reorder_spatial(tsp_context *ctx, int n_strata, uint64_t seed, int64_t *perm_out);
+int ensure_weights(tsp_context *ctx, bool rgb);    // (re)computes p.wm or p.wr / wg / wb on ctx->stream when the particles changed
 int ensure_block_bounds(tsp_context *ctx);     // (re)computes ws.block_bounds on ctx->stream when the particles changed
 int measure_read_bandwidth(tsp_context *ctx, int64_t bytes, int iters, double *gbps_out);
 int launch_image_convert(tsp_context *ctx, bool to_float);

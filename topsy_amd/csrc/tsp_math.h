@@ -35,6 +35,7 @@ struct Proj {            // a particle in pixel units
     bool keep;
 };
 
+template <bool WITH_INVP = true>
 __device__ __forceinline__ Proj project(const Camera &c, float x, float y, float z, float h) {
     Proj r;
     const float cx = ((c.m[0] * x + c.m[1] * y) + c.m[2] * z) + c.m[3];
@@ -45,7 +46,7 @@ __device__ __forceinline__ Proj project(const Camera &c, float x, float y, float
     r.half = 0.5f * r.P;
     r.pcx = (cx + 1.0f) * c.halfR;
     r.pcy = (1.0f - cy) * c.halfR;
-    r.invP = 1.0f / r.P;
+    r.invP = WITH_INVP ? 1.0f / r.P : 0.0f;      // (kernel S forms it only in the waves that rasterise)
     // fixed-function clip: 0 <= z <= 1; non-finite geometry draws nothing
     r.keep = (r.cz >= 0.0f) && (r.cz <= 1.0f) && (r.P > 0.0f) && (r.P < __builtin_inff()) &&
              (__builtin_fabsf(r.pcx) < __builtin_inff()) && (__builtin_fabsf(r.pcy) < __builtin_inff());

@@ -16,7 +16,7 @@ constexpr int SBLOCK = TSP_S_BLOCK;  // threads per workgroup of kernel S
 constexpr int SWAVES = SBLOCK / 64;
 constexpr int KPT = TSP_S_KPT;       // particles per thread per chunk
 constexpr int CHUNK = SBLOCK * KPT;  // particles per chunk
-constexpr int TILE = 64;             // image tile edge of kernel H (and tile width of kernel M)
+constexpr int TILE = 64;             // tile width of kernel M
 // tile height of kernel M by the number of channels in its LDS tile: 64 x 32 pixels for a density render; 64 x 16 with
 // two or three channels, so that two (rgb) or three workgroups still fit a CU's LDS (rgb: M 31.9 -> 21.0 ms)
 constexpr int mtile_h(int wc) { return wc == 1 ? 32 : 16; }
@@ -53,7 +53,7 @@ __device__ __forceinline__ void latomic_add(double *addr, float v) {
 }
 
 #ifndef TSP_FOLD_EVERY
-#define TSP_FOLD_EVERY 512     // footprints a float32 accumulator of kernels H2 / H3 holds before it goes to the float64 target
+#define TSP_FOLD_EVERY 512     // footprints a float32 accumulator of kernel H2 holds before it goes to the float64 target
 #endif
 #ifndef TSP_HDEAL
 #define TSP_HDEAL 16
@@ -70,21 +70,39 @@ struct TileArgs {
     double *img;
     Counters *cnt;
     int tiles_x, split;
+    int n_tiles, xcd_group;   // workgroup -> (tile, split) mapping: see tile_and_split()
     int count_frag;
     float disc_k2;     // (0.5235)^2 when the LUT is zero outside the inscribed disc (exact corner culling), else 0
-    float p_lo, p_hi;  // kernels H2 / H3 take the records with p_lo <= P < p_hi
+    float p_lo, p_hi;  // kernel H2 takes the records with p_lo <= P < p_hi
 };
 
-// Kernels H / H2 / H3 (tsp_gather.hip) for the footprints >= 64 px of one render block: `huge_*` = the records with
-// 64 px <= P < p_mega (all of them in rgb mode), `mega_*` = the records with P >= p_mega.  Records ctx->ev[10] between
-// the two launches and ctx->ev[11] after them (per-kernel times).
+// Which (tile, slice of the record list) a workgroup of the tile kernels takes.  Blocks go to the eight XCDs round-robin
+// (block b runs on XCD b % 8: observed, used for speed only) and each XCD has its own 4 MiB L2.  With b = tile * split + sp
+// (rounds 1-4) slice sp is always read on XCD sp % 8, but by one tile at a time: every tile re-fetched the whole list through
+// the fabric (kernel H2 at 1e9 particles: 12.7 GB of reads per launch for an 85 MB list).  Here the slices keep their XCD
+// (sp % 8 == b % 8) and an XCD walks `xcd_group` tiles per slice before the next slice: the workgroups resident on an XCD at
+// one time read the same few slices -- one miss per line and XCD per tile group.  Tiles stay in row-major groups, so the
+// launch still ends on the light bottom rows.  xcd_group = 0 (or a split that is no multiple of 8): the old mapping.
+__device__ __forceinline__ void tile_and_split(unsigned b, int split, int n_tiles, int xcd_group, int &tile, int &sp) {
+    if (xcd_group <= 0 || (split & 7) != 0) { tile = (int)(b / (unsigned)split); sp = (int)(b % (unsigned)split); return; }
+    const unsigned x = b & 7u, q = b >> 3, s8 = (unsigned)split >> 3, per_group = (unsigned)xcd_group * s8;
+    const unsigned g = q / per_group, r = q - g * per_group;
+    const unsigned gsize = min((unsigned)xcd_group, (unsigned)n_tiles - g * (unsigned)xcd_group);
+    const unsigned si = r / gsize;
+    tile = (int)(g * (unsigned)xcd_group + (r - si * gsize));
+    sp = (int)(si * 8u + x);
+}
+
+// Kernel H2 (tsp_gather.hip) for the footprints >= 64 px of one render block: `huge_*` = the records below the option
+// integrated_px (all of them by default), `mega_*` = the records at least that wide, which kernel I draws.  Records ctx->ev[10]
+// between the two launches and ctx->ev[11] after them (per-kernel times).
 int launch_gather_kernels(tsp_context *ctx, TileArgs ta, int mode, bool second_channel, const float4 *huge_geom,
                           const float *huge_w, long long n_huge, const float4 *mega_geom, const float *mega_w, long long n_mega);
 
 // Kernel I (tsp_integrated.hip, option `integrated_px`): the mega records through second differences, one pass per channel.
 int launch_integrated(tsp_context *ctx, const TileArgs &ta, const float4 *geom, const float *wq, int wmode, long long n_records, float p_lo);
 inline bool integrated_active(const tsp_context *ctx) {
-    return ctx->integrated_px >= 128.0f && ctx->huge_variant != 0 && integrated_supported(ctx);
+    return ctx->integrated_px >= 128.0f && integrated_supported(ctx);
 }
 
 }  // namespace tsp

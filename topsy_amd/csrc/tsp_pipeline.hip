@@ -18,8 +18,8 @@
 //             mip level), then each wave rasterises its records one at a time, parameters broadcast
 //             into scalar registers, 8x8 lanes per step, nearest-mip sampling from an LDS copy of the
 //             mip pyramid, ds_add_f64 into the LDS tile (row stride 72: distinct addresses per step).
-//   kernels H / H2 / H3 (tsp_gather.hip) take the footprints >= 64 px (bilinear sampling): per-wave pixel strips held in
-//             registers, records scanned per wave, no atomics in the loop; H3 runs the >= 512 px ones on the matrix cores.
+//   kernel H2 (tsp_gather.hip) takes the footprints >= 64 px (bilinear sampling): per-wave pixel strips held in
+//             registers, records scanned per wave, no atomics in the loop.
 //
 // All of them add into the float64 render target with device-scope atomics only at flush time.
 #include <string.h>
@@ -103,7 +103,7 @@ struct StreamArgs {
     int *band_count; int *band_list; long long band_cap; int band_h;     // per image band: the chunks that have mid footprints there
     Counters *cnt;
     float p_small;
-    float p_mega;              // footprints at least this wide are appended from the END of the huge list (kernel H3's share)
+    float p_mega;              // footprints at least this wide are appended from the END of the huge list (kernel I's share, option integrated_px; else +inf)
     int count_frag;
     int emit_small;            // 0: records only (replay after a record-list overflow)
     const int *alive;          // chunk culling: the chunks that may reach the view, nullptr = every chunk
@@ -325,9 +325,11 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
     auto load_chunk = [&](int64_t first, int cnt) {
         CArgs *ap = KA();
         const float *qx = ap->p.x, *qy = ap->p.y, *qz = ap->p.z, *qh = ap->p.h;
-        const float *q4 = (MODE == TSP_MODE_RGB) ? ap->p.r : ap->p.m;
-        const float *q5 = (MODE == TSP_MODE_RGB) ? ap->p.g : ((MODE != TSP_MODE_DEPTH) ? ap->p.q : nullptr);
-        const float *q6 = (MODE == TSP_MODE_RGB) ? ap->p.b : nullptr;
+        // the camera-independent weights m / h^2 (rgb: r, g, b over h^2) are formed once per upload (ensure_weights): the
+        // same float32 operations on the same operands as sph.wgsl:76-83, done once instead of every frame
+        const float *q4 = (MODE == TSP_MODE_RGB) ? ap->p.wr : ap->p.wm;
+        const float *q5 = (MODE == TSP_MODE_RGB) ? ap->p.wg : ((MODE != TSP_MODE_DEPTH) ? ap->p.q : nullptr);
+        const float *q6 = (MODE == TSP_MODE_RGB) ? ap->p.wb : nullptr;
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
             // lanes past the end of a short chunk load its last particle again (cnt >= 1): no predication, no zero fill;
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         // ---- phase 1: projection, exact covered pixel ranges, classification ------------------------------------
         // Bounding boxes are kept as PACKED 16-bit pixel pairs (x | y << 16; the image has <= 16384 pixels per side):
         // one v_pk_min_u16 / v_pk_max_u16 per reduction step does both axes.
-        float pcx[KPT], pcy[KPT], PP[KPT], invP[KPT], w0[KPT], w1[KPT], w2[KPT];
+        float pcx[KPT], pcy[KPT], PP[KPT], w0[KPT], w1[KPT], w2[KPT];
         int cls[KPT];
         unsigned xr[KPT], yr[KPT];     // first covered pixel | (number of covered pixels << 16), clipped to the image
         unsigned s_lo = 0xffffffffu, s_hi = 0u;      // covered-pixel bounding box of the small footprints: (ilo | jlo << 16), (ihi | jhi << 16)
@@ -376,7 +378,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
             const int li = k * SBLOCK + tid;
             const bool in_chunk = li < cnt;
             const float h = L[k][3];
-            const Proj pr = project(cam, L[k][0], L[k][1], L[k][2], h);
+            const Proj pr = project<false>(cam, L[k][0], L[k][1], L[k][2], h);
             int ilo = 1, ihi = 0, jlo = 1, jhi = 0;
             if (__ballot(in_chunk && pr.keep) != 0ull) {        // (a chunk wholly outside the z-slab skips the range arithmetic)
                 // any pixel centre covered?  (exact test via the canonical interval)
@@ -388,15 +390,14 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
             xr[k] = (unsigned)ilo | ((unsigned)min(ihi - ilo + 1, 0xffff) << 16);
             yr[k] = (unsigned)jlo | ((unsigned)min(jhi - jlo + 1, 0xffff) << 16);
             const unsigned lo = (unsigned)ilo | ((unsigned)jlo << 16), hi = (unsigned)ihi | ((unsigned)jhi << 16);
-            const float hh = h * h;
             if (MODE == TSP_MODE_RGB) {
-                w0[k] = L[k][4] / hh; w1[k] = L[k][5] / hh; w2[k] = L[k][NATTR - 1] / hh;
+                w0[k] = L[k][4]; w1[k] = L[k][5]; w2[k] = L[k][NATTR - 1];
             } else {
-                w0[k] = L[k][4] / hh;
+                w0[k] = L[k][4];
                 w1[k] = (MODE == TSP_MODE_DEPTH) ? pr.cz : L[k][5];
                 w2[k] = 0.0f;
             }
-            pcx[k] = pr.pcx; pcy[k] = pr.pcy; PP[k] = pr.P; invP[k] = pr.invP;
+            pcx[k] = pr.pcx; pcy[k] = pr.pcy; PP[k] = pr.P;      // (1 / P is formed in phase 4, by the waves that rasterise)
             const int c_of_p = (pr.P < p_small) ? CLS_SMALL : ((pr.P < P_BILINEAR) ? CLS_MID : ((pr.P < p_mega) ? CLS_HUGE : CLS_MEGA));
             cls[k] = vis ? c_of_p : CLS_NONE;          // CLS_MEGA is rare (~1e-3 of the particles): one atomic each, below
             const bool is_small = cls[k] == CLS_SMALL, is_mid = cls[k] == CLS_MID;
@@ -464,14 +465,16 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
             counts_total += s_cnt[w];
         }
         const int mid_total = counts_total & 0xffff, huge_total = counts_total >> 16;
-        // reserve contiguous runs in the record lists (one atomic per chunk and list)
+        // reserve contiguous runs in the record lists (one atomic per chunk and list).  The returning atomics are ISSUED here and
+        // their results are published after phase 4: the round trip to L2 (and the wait for the next chunk's attribute loads
+        // queued before it) overlaps the rasteriser instead of holding all four waves at a barrier
+        long long r_mid = 0, r_huge = 0;
         if (tid == 0) {
             CArgs *ap = KA();
             Counters *cntp = ap->cnt;
-            s_base[0] = mid_total ? (long long)atomicAdd(&cntp->n_mid, (unsigned long long)mid_total) : 0;
-            s_base[1] = huge_total ? (long long)atomicAdd(&cntp->n_huge, (unsigned long long)huge_total) : 0;
+            if (mid_total) r_mid = (long long)atomicAdd(&cntp->n_mid, (unsigned long long)mid_total);
+            if (huge_total) r_huge = (long long)atomicAdd(&cntp->n_huge, (unsigned long long)huge_total);
             ap->seg_count[c] = mid_total;
-            ap->seg_offset[c] = s_base[0];
             if (mid_total) {
                 // covered-pixel bounds [x0, x1] x [y0, y1] stored as (x0, y0, x1 + 1, y1 + 1): kernel M's tile test
                 // bb.x < tile_x1 && bb.z > tile_x0 is then exact for integer tile edges
@@ -481,13 +484,11 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                 ap->seg_bbox[c] = make_float4((float)(lo & 0xffffu), (float)(lo >> 16), (float)((hi & 0xffffu) + 1u), (float)((hi >> 16) + 1u));
             }
         }
-        __syncthreads();
-        const long long mid_base = s_base[0], huge_base = s_base[1];
         if (tid == SBLOCK - 1 && mid_total) {
             // Kernel M's workgroups look only at the chunks of their own image band: one or two appends per chunk here against
-            // a scan of every chunk header by every tile there.  Done by the LAST thread after the barrier, off the
-            // workgroup's critical path (the returning atomic costs a round trip to L2 that only this wave waits for;
-            // s_mbb is not rewritten before the next chunk's first barrier).  Aggregating the appends per workgroup (one
+            // a scan of every chunk header by every tile there.  Done by the LAST thread, off the workgroup's critical path
+            // (the returning atomic costs a round trip to L2 that only this wave waits for; s_mbb is not rewritten before
+            // the next chunk's second barrier).  Aggregating the appends per workgroup (one
             // atomic per workgroup and band) measured slower: +0.15 ms on this kernel for its two extra barriers.
             unsigned lo = s_mbb[0][0], hi = s_mbb[0][1];
 #pragma unroll
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
             if (__ballot(act) == 0ull) continue;
             const int nx = act ? (int)(xr[k] >> 16) : 0, ny = act ? (int)(yr[k] >> 16) : 0;
             const int ilo = (int)(xr[k] & 0xffffu), jlo = (int)(yr[k] & 0xffffu);
-            const float half = 0.5f * PP[k], ip = invP[k];
+            const float half = 0.5f * PP[k], ip = 1.0f / PP[k];      // project(): invP = 1 / P (deferred records carry P, not 1 / P)
             // mip 3 (8 x 8) up to 11.3 px, mip 2 (16 x 16) above (p_small may reach 15 px)
             const bool lvl2 = PP[k] > P_L2;
             const float nf = lvl2 ? 16.0f : 8.0f;
@@ -634,6 +635,12 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         }
 
         // ---- phase 5: append the deferred footprints -----------------------------------------------
+        if (tid == 0) {
+            s_base[0] = r_mid; s_base[1] = r_huge;
+            KA()->seg_offset[c] = r_mid;
+        }
+        __syncthreads();
+        const long long mid_base = s_base[0], huge_base = s_base[1];
         {
             CArgs *ap = KA();
             float4 *const mid_geom = ap->mid_geom, *const huge_geom = ap->huge_geom;
@@ -719,7 +726,8 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
     __shared__ int s_wcnt[MT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int R = a.cam.R;
-    const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
+    int tile_id, sp;
+    tile_and_split(blockIdx.x, a.split, a.n_tiles, a.xcd_group, tile_id, sp);
     const int tx0 = (tile_id % a.tiles_x) * TILE, ty0 = (tile_id / a.tiles_x) * MTILE_H;
     const float fx0 = (float)tx0, fy0 = (float)ty0, fx1 = (float)(tx0 + TILE), fy1 = (float)(ty0 + MTILE_H);
     if (QUAD) {
@@ -881,7 +889,7 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
 // ---------------------------------------------------------------------------------------------
 // fragment_rgb writes (k r, k g, k b, 1): channel 3 counts the footprint SQUARES covering a pixel, also where
 // the kernel value is exactly 0.  Per footprint that is the indicator of a pixel rectangle, so instead of one add
-// per fragment kernels M and H leave the channel alone (H may then skip whatever lies outside the kernel's disc,
+// per fragment kernels M and H2 leave the channel alone (H2 may then skip whatever lies outside the kernel's disc,
 // M saves a quarter of its LDS atomics) and the rectangles are summed exactly in integers: +-1 at the four corners of each rectangle, then a 2-D prefix
 // sum, added to the float64 render target.
 __global__ __launch_bounds__(256) void rect_count_corners_kernel(const float4 *__restrict__ geom, long long n, int R, int *__restrict__ D) {
@@ -1026,6 +1034,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     const int band_h = (((ctx->R + NBANDS - 1) / NBANDS + 31) / 32) * 32;
     // record lists: start modest, grow to the exact need when a frame overflows (rare)
     int rc;
+    if ((rc = ensure_weights(ctx, MODE == TSP_MODE_RGB))) return rc;      // m / h^2 (rgb / h^2): once per upload, not per frame
     if (ws.mid_capacity == 0) {
         const int64_t guess = std::max<int64_t>(total / 4, 1 << 16);
         if ((rc = grow(&ws.mid_geom, &ws.mid_capacity, guess, sizeof(float4)))) return rc;
@@ -1117,11 +1126,10 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         sa.seg_count = ws.seg_count; sa.seg_offset = ws.seg_offset; sa.seg_bbox = ws.seg_bbox;
         sa.band_count = ws.band_count; sa.band_list = ws.band_list; sa.band_cap = ws.band_capacity; sa.band_h = band_h;
         TSP_HIP(hipMemsetAsync(ws.band_count, 0, NBANDS * sizeof(int), st));
-        sa.cnt = ctx->counters; sa.p_small = ctx->p_small; {
-            float pm = (MODE == TSP_MODE_RGB) ? (ctx->rgb_mega_variant > 0 ? ctx->p_mega_rgb : 0.0f) : (second_channel ? ctx->p_mega2 : ctx->p_mega);
-            if (integrated_active(ctx)) pm = (pm > 0.0f && pm < ctx->integrated_px) ? pm : ctx->integrated_px;     // kernel I takes the mega records >= integrated_px
-            sa.p_mega = (ctx->huge_variant != 0 && pm > 0.0f) ? pm : __builtin_inff();
-        } sa.count_frag = ctx->count_fragments ? 1 : 0;
+        sa.cnt = ctx->counters; sa.p_small = ctx->p_small;
+        // option integrated_px: the records at least that wide grow from the END of the huge list and go to kernel I
+        sa.p_mega = integrated_active(ctx) ? ctx->integrated_px : __builtin_inff();
+        sa.count_frag = ctx->count_fragments ? 1 : 0;
         sa.emit_small = (attempt == 0 && !ctx->debug_no_raster) ? 1 : 0;
         TSP_HIP(hipEventRecord(ctx->ev[2], st));
         if (WCr == 1) hipLaunchKernelGGL((splat_stream_kernel<MODE, 1>), dim3(grid_s), dim3(SBLOCK), smem_s, st, sa);
@@ -1164,9 +1172,9 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     ta.cam = cam; ta.mips = ctx->mips; ta.img = ctx->image64; ta.cnt = ctx->counters; ta.tiles_x = tiles_x;
     ta.count_frag = ctx->count_fragments ? 1 : 0;
     // corner culling is exact for the value channels; the rgb counter channel (which also counts zero-valued
-    // fragments) is not touched by kernel H at all: add_rect_counts() sums the footprint rectangles instead
+    // fragments) is not touched by kernel H2 at all: add_rect_counts() sums the footprint rectangles instead
     ta.disc_k2 = (ctx->lut_zero_outside_disc && !ctx->count_fragments) ? 0.5235f * 0.5235f : 0.0f;
-    // Kernel M (LDS-atomic-bound) and kernel H (VALU-bound) only depend on kernel S and add into the
+    // Kernel M (LDS-atomic-bound) and kernel H2 (VALU-bound) only depend on kernel S and add into the
     // float64 image with atomics, so they run concurrently on two streams and share the CUs.
     hipStream_t st_mid = ctx->overlap_mid_huge ? ctx->stream2 : st;
     if (ctx->overlap_mid_huge) {
@@ -1180,6 +1188,8 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         // a small render block (an interactive frame's first 1e5 particles leave ~3e4 records) does not need 65 536
         // workgroups that each load the LUT: fewer splits in proportion below 2^18 records
         if ((long long)hc.n_mid < (1ll << 18)) ta.split = std::max(4, (int)((long long)ta.split * (long long)hc.n_mid >> 18));
+        // (one tile row = the tiles that share a band's chunk list: the XCD-aware order walks a row per slice)
+        ta.n_tiles = tiles_x * mtiles_y; ta.xcd_group = ctx->xcd_group_mid >= 0 ? ctx->xcd_group_mid : (ctx->xcd_group > 0 ? tiles_x : 0);
         const dim3 grid_m(tiles_x * mtiles_y * ta.split);
         if (WCr == 1 && quad) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1, true>), grid_m, dim3(MT), smem_m, st_mid, ta);
         else if (WCr == 1) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1, false>), grid_m, dim3(MT), smem_m, st_mid, ta);

@@ -112,7 +112,9 @@ class SPH:
         M, sf = self._transform
         buffers = self._visualizer.particle_buffers
         clear = rp.start_frame(draw_reason)
+        n_blocks = 0
         while block := rp.get_block(self._render_timer.total_time_in_frame()):
+            n_blocks += 1
             # a block is charged its wall-clock time (host work included), as the reference's TimeGpuOperation does
             with self._render_timer.block() as timed:
                 buffers.update_particle_ranges(*block)
@@ -128,6 +130,7 @@ class SPH:
         mean = self._render_timer.running_mean_duration
         self.last_render_fps = 1.0 / mean if mean > 0 else float("inf")
         self.has_rendered = True
+        self.last_render_blocks = n_blocks        # tsp_render calls of this frame (EXPORT: one on this backend)
         self._visualizer.particle_buffers.last_renderer = self
         return True
 
