@@ -268,14 +268,20 @@ int tsp_comm_init(tsp_context *ctx, int n_ranks, int rank, const char *id);
  * On ranks other than `root` the image content after the call is unspecified (root >= 0). */
 int tsp_comm_reduce_image(tsp_context *ctx, int root, double *gpu_ms_out);
 int tsp_comm_destroy(tsp_context *ctx);
+/* The same hand-over for a collective the CALLER performed (shards summed through the host: contexts that share a device,
+ * which RCCL refuses, or no RCCL at all): `sum` (R * R * C float32) becomes the float32 presentation image of `ctx`; its
+ * float64 accumulator keeps the context's own partial sums, so a later tsp_render with clear = 0 continues unrounded --
+ * exactly the state tsp_comm_reduce_image leaves on the root.  Same once-per-frame rule (TSP_ESTATE on a second call). */
+int tsp_set_reduced_image(tsp_context *ctx, const float *sum);
 
 /* Several GPUs of one node behind ONE handle (SURVEY.md section 8b sketched `tsp_create(n_devices, device_ids, ...)`; the
  * reference has no counterpart -- its SplitBuffers, src/topsy/split_buffers.py:26-38,78-116, cuts one device's buffers the same
  * way).  A group is n_devices ordinary contexts plus the host-thread choreography: uploads are cut into the contiguous index
  * ranges [g N / G, (g + 1) N / G), tsp_group_render intersects the block's (start, len) ranges with every shard and runs the
  * G tsp_render calls concurrently (returns the slowest shard's GPU time), and tsp_group_end_frame is the frame's ONE sum-reduce
- * of the float32 image onto context 0 -- RCCL over xGMI when the device ids are distinct, a read-back / add / write-back through
- * the host when two contexts share a device (RCCL refuses that; single-GPU test boxes).  Everything that looks at the finished
+ * of the float32 image onto context 0 -- RCCL over xGMI when the device ids are distinct, a read-back / add of the float32
+ * partial images through the host and tsp_set_reduced_image when two contexts share a device (RCCL refuses that; single-GPU test
+ * boxes) or librccl cannot be loaded.  Everything that looks at the finished
  * frame (tsp_read_image, tsp_colormap_*, tsp_content_*, tsp_tile_periodic) is called on tsp_group_context(group, 0) after
  * tsp_group_end_frame; per-shard state can be inspected through tsp_group_context(group, g).  The reduce contract of
  * tsp_comm_reduce_image holds: end_frame reduces at most once per rendered frame, and a later tsp_group_render -- a REFINE
@@ -301,6 +307,10 @@ int tsp_group_render(tsp_group *group, const float *M, float scale_factor, const
                      int n_ranges, int clear, int mode, int flags, double *gpu_ms_out);
 int tsp_group_end_frame(tsp_group *group, double *ms_out);
 int tsp_group_get_stats(tsp_group *group, tsp_stats *out);
+/* Shard `index` owns the global indices [*first_out, *first_out + *count_out) of the last upload / generate. */
+int tsp_group_shard_range(tsp_group *group, int index, int64_t *first_out, int64_t *count_out);
+/* tsp_upload_band_magnitudes for the group: mags is [n_bands][N] over the whole snapshot, every shard takes its columns. */
+int tsp_group_upload_band_magnitudes(tsp_group *group, int n_bands, const double *mags, const double *weights);
 
 #ifdef __cplusplus
 }

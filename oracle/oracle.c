@@ -206,6 +206,10 @@ static inline void particle_weights(float *w, int mode, proj_t pr, float hp, con
  * starts/lens: particle index ranges (NULL -> all), drawn in the order given (particle_buffers.py:70-82).
  * out: R*R*C float32 (C = 2 or 4).  accumulate != 0 adds to `out` instead of overwriting.
  * Returns the total fragment count. */
+#ifndef ORC_BATCH
+#define ORC_BATCH 10000000      /* particles per batch of the tile-parallel splat (bounds the (particle, tile) entry list) */
+#endif
+
 long orc_splat_rule(long n, const float *x, const float *y, const float *z, const float *h,
                     const float *a, const float *b, const float *c, int mode,
                     const float *M, float sf, int R, const float *mips,
@@ -223,6 +227,7 @@ long orc_splat_rule(long n, const float *x, const float *y, const float *z, cons
     const int nt = (R + TS - 1) / TS;                      /* tiles per image side */
     /* the drawing sequence: ranges in the order given, clipped to [0, n) */
     int64_t *rbeg = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nranges + 1) * 2);
+    if (!rbeg) return -1;
     int64_t *roff = rbeg + nranges + 1;
     int64_t nsel = 0;
     for (int r = 0; r < nranges; ++r) {
@@ -235,15 +240,30 @@ long orc_splat_rule(long n, const float *x, const float *y, const float *z, cons
         nsel += end - beg;
     }
     roff[nranges] = nsel;
-    /* pass A: tile rectangle of every drawn particle (x0 > x1 = draws nothing) */
+    /* The drawing sequence is processed in BATCHES of at most ORC_BATCH particles (the per-(particle, tile) entry list of
+     * one batch stays bounded: a 1000-px footprint spans ~1000 tiles of 32 x 32 px).  Every tile's terms are still added in
+     * drawing order into ONE float64 accumulator image that lives across the batches, so the sequence of float64 additions per
+     * pixel -- and with it the result, bit for bit -- is that of a single pass (and independent of the thread count).
+     * A failed allocation returns -1 (the Python wrapper raises MemoryError). */
     typedef struct { uint16_t x0, x1, y0, y1; } box_t;
-    box_t *box = (box_t *)malloc(sizeof(box_t) * (size_t)(nsel > 0 ? nsel : 1));
-    for (int r = 0; r < nranges; ++r) {
-        const int64_t beg = rbeg[r], cnt = roff[r + 1] - roff[r];
-        box_t *bx = box + roff[r];
+    const int64_t batch_cap = nsel < ORC_BATCH ? (nsel > 0 ? nsel : 1) : ORC_BATCH;
+    box_t *box = (box_t *)malloc(sizeof(box_t) * (size_t)batch_cap);
+    int64_t *tcount = (int64_t *)malloc(sizeof(int64_t) * ((size_t)nt * nt + 1));
+    int64_t *tstart = (int64_t *)malloc(sizeof(int64_t) * ((size_t)nt * nt + 1));
+    double *accimg = (double *)calloc((size_t)R * R * C, sizeof(double));
+    int64_t *entries = NULL;
+    int64_t entries_cap = 0;
+    long total_frag = 0;
+    int failed = (!rbeg || !box || !tcount || !tstart || !accimg);
+    for (int64_t f0 = 0; f0 < nsel && !failed; f0 += batch_cap) {
+        const int64_t nb = (nsel - f0 < batch_cap) ? nsel - f0 : batch_cap;
+        /* pass A: tile rectangle of every particle of the batch (x0 > x1 = draws nothing) */
 #pragma omp parallel for schedule(static) num_threads(nthreads)
-        for (int64_t k = 0; k < cnt; ++k) {
-            const int64_t p = beg + k;
+        for (int64_t k = 0; k < nb; ++k) {
+            const int64_t f = f0 + k;
+            int r = 0;                                           /* range of sequence position f (binary search) */
+            { int lo = 0, hi = nranges - 1; while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (roff[mid] <= f) lo = mid; else hi = mid - 1; } r = lo; }
+            const int64_t p = rbeg[r] + (f - roff[r]);
             box_t q = {1, 0, 1, 0};
             proj_t pr = orc_project(M, sf, Rf, x[p], y[p], z[p], h[p]);
             if (pr.keep) {
@@ -255,72 +275,81 @@ long orc_splat_rule(long n, const float *x, const float *y, const float *z, cons
                     q.y0 = (uint16_t)(jlo / TS); q.y1 = (uint16_t)(jhi / TS);
                 }
             }
-            bx[k] = q;
+            box[k] = q;
         }
-    }
-    /* pass B: per tile, the positions (in the drawing sequence) of the particles that reach it, ascending.
-     * One thread per tile ROW scans the boxes twice (count, fill): no atomics, order preserved. */
-    int64_t *tcount = (int64_t *)calloc((size_t)nt * nt + 1, sizeof(int64_t));
+        /* pass B: per tile, the positions (in the drawing sequence) of the batch's particles that reach it, ascending.
+         * One thread per tile ROW scans the boxes twice (count, fill): no atomics, order preserved. */
+        memset(tcount, 0, sizeof(int64_t) * ((size_t)nt * nt + 1));
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
-    for (int ty = 0; ty < nt; ++ty) {
-        int64_t *cn = tcount + (size_t)ty * nt;
-        for (int64_t f = 0; f < nsel; ++f) {
-            const box_t q = box[f];
-            if (q.x0 > q.x1 || ty < q.y0 || ty > q.y1) continue;
-            for (int tx = q.x0; tx <= q.x1; ++tx) ++cn[tx];
+        for (int ty = 0; ty < nt; ++ty) {
+            int64_t *cn = tcount + (size_t)ty * nt;
+            for (int64_t k = 0; k < nb; ++k) {
+                const box_t q = box[k];
+                if (q.x0 > q.x1 || ty < q.y0 || ty > q.y1) continue;
+                for (int tx = q.x0; tx <= q.x1; ++tx) ++cn[tx];
+            }
         }
-    }
-    int64_t *tstart = (int64_t *)malloc(sizeof(int64_t) * ((size_t)nt * nt + 1));
-    int64_t total = 0;
-    for (int t = 0; t < nt * nt; ++t) { tstart[t] = total; total += tcount[t]; }
-    tstart[nt * nt] = total;
-    int64_t *entries = (int64_t *)malloc(sizeof(int64_t) * (size_t)(total > 0 ? total : 1));
-    memcpy(tcount, tstart, sizeof(int64_t) * (size_t)nt * nt);      /* reused as the fill cursors */
+        int64_t total = 0;
+        for (int t = 0; t < nt * nt; ++t) { tstart[t] = total; total += tcount[t]; }
+        tstart[nt * nt] = total;
+        if (total > entries_cap) {
+            free(entries);
+            entries_cap = total + total / 4 + 1024;
+            entries = (int64_t *)malloc(sizeof(int64_t) * (size_t)entries_cap);
+            if (!entries) { failed = 1; break; }
+        }
+        memcpy(tcount, tstart, sizeof(int64_t) * (size_t)nt * nt);      /* reused as the fill cursors */
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
-    for (int ty = 0; ty < nt; ++ty) {
-        int64_t *cur = tcount + (size_t)ty * nt;
-        for (int64_t f = 0; f < nsel; ++f) {
-            const box_t q = box[f];
-            if (q.x0 > q.x1 || ty < q.y0 || ty > q.y1) continue;
-            for (int tx = q.x0; tx <= q.x1; ++tx) entries[cur[tx]++] = f;
+        for (int ty = 0; ty < nt; ++ty) {
+            int64_t *cur = tcount + (size_t)ty * nt;
+            for (int64_t k = 0; k < nb; ++k) {
+                const box_t q = box[k];
+                if (q.x0 > q.x1 || ty < q.y0 || ty > q.y1) continue;
+                for (int tx = q.x0; tx <= q.x1; ++tx) entries[cur[tx]++] = f0 + k;
+            }
         }
-    }
-    free(box);
-    /* pass C: one thread per tile, terms added in drawing order */
-    long total_frag = 0;
+        /* pass C: one thread per tile, terms added in drawing order into the tile's part of the float64 accumulator image */
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) reduction(+ : total_frag)
-    for (int t = 0; t < nt * nt; ++t) {
-        const int ty = t / nt, tx = t % nt;
-        const int x0 = tx * TS, y0 = ty * TS;
-        const int x1 = (x0 + TS - 1 < R - 1) ? x0 + TS - 1 : R - 1;
-        const int y1 = (y0 + TS - 1 < R - 1) ? y0 + TS - 1 : R - 1;
-        double acc[TS * TS * 4];
-        memset(acc, 0, sizeof(double) * TS * TS * C);
-        long nf = 0;
-        int r = 0;
-        for (int64_t e = tstart[t]; e < tstart[t + 1]; ++e) {
-            const int64_t f = entries[e];
-            while (f >= roff[r + 1]) ++r;                    /* entries ascend: the range index only moves forward */
-            const int64_t p = rbeg[r] + (f - roff[r]);
-            proj_t pr = orc_project(M, sf, Rf, x[p], y[p], z[p], h[p]);
-            float w[3];
-            particle_weights(w, mode, pr, h[p], a, b, c, p);
-            splat_tile(acc, x0, x1, y0, y1, R, C, mips, pr, w, &nf, rule);
+        for (int t = 0; t < nt * nt; ++t) {
+            if (tstart[t] == tstart[t + 1]) continue;
+            const int ty = t / nt, tx = t % nt;
+            const int x0 = tx * TS, y0 = ty * TS;
+            const int x1 = (x0 + TS - 1 < R - 1) ? x0 + TS - 1 : R - 1;
+            const int y1 = (y0 + TS - 1 < R - 1) ? y0 + TS - 1 : R - 1;
+            double acc[TS * TS * 4];
+            for (int j = y0; j <= y1; ++j)
+                for (int i = x0; i <= x1; ++i)
+                    for (int k = 0; k < C; ++k)
+                        acc[((size_t)(j - y0) * TS + (i - x0)) * C + k] = accimg[((size_t)j * R + i) * C + k];
+            long nf = 0;
+            int r = 0;
+            for (int64_t e = tstart[t]; e < tstart[t + 1]; ++e) {
+                const int64_t f = entries[e];
+                while (f >= roff[r + 1]) ++r;                    /* entries ascend: the range index only moves forward */
+                const int64_t p = rbeg[r] + (f - roff[r]);
+                proj_t pr = orc_project(M, sf, Rf, x[p], y[p], z[p], h[p]);
+                float w[3];
+                particle_weights(w, mode, pr, h[p], a, b, c, p);
+                splat_tile(acc, x0, x1, y0, y1, R, C, mips, pr, w, &nf, rule);
+            }
+            total_frag += nf;
+            for (int j = y0; j <= y1; ++j)
+                for (int i = x0; i <= x1; ++i)
+                    for (int k = 0; k < C; ++k)
+                        accimg[((size_t)j * R + i) * C + k] = acc[((size_t)(j - y0) * TS + (i - x0)) * C + k];
         }
-        total_frag += nf;
-        for (int j = y0; j <= y1; ++j)
-            for (int i = x0; i <= x1; ++i)
-                for (int k = 0; k < C; ++k) {
-                    const size_t o = ((size_t)j * R + i) * C + k;
-                    const double s = acc[((size_t)(j - y0) * TS + (i - x0)) * C + k];
-                    out[o] = accumulate ? (float)((double)out[o] + s) : (float)s;
-                }
+    }
+    if (!failed) {
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+        for (int64_t o = 0; o < (int64_t)R * R * C; ++o) out[o] = accumulate ? (float)((double)out[o] + accimg[o]) : (float)accimg[o];
     }
     free(entries);
+    free(accimg);
     free(tstart);
     free(tcount);
+    free(box);
     free(rbeg);
-    return total_frag;
+    return failed ? -1 : total_frag;
 }
 
 /* the reference's sampling (rule "O1") */

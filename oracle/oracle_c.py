@@ -83,6 +83,8 @@ def splat(x, y, z, h, a, b=None, c=None, *, mode=0, M, sf, R, mips, ranges=None,
         sp, lp, nr = s.ctypes.data_as(_ip), l.ctypes.data_as(_ip), len(s)
     nfrag = L.orc_splat_rule(n, *[k[1] for k in keep], mode, Mp, ctypes.c_float(sf), R, mp, sp, lp, nr,
                              accumulate, nthreads, out.ctypes.data_as(_fp), int(sampling))
+    if nfrag < 0:
+        raise MemoryError("oracle.c: an allocation failed (orc_splat_rule returned -1)")
     return out, nfrag
 
 

@@ -46,6 +46,7 @@ def test_group_frame_equals_one_context(native, mips, devices):
     grp.generate_synthetic(n, 0, n, 1337, 0.0, with_quantity=True)
     assert grp.num_particles == n
     assert [grp.member(g).num_particles for g in range(grp.size)] == [(n * (g + 1)) // grp.size - (n * g) // grp.size for g in range(grp.size)]
+    assert [grp.shard_range(g) for g in range(grp.size)] == [((n * g) // grp.size, (n * (g + 1)) // grp.size - (n * g) // grp.size) for g in range(grp.size)]
     grp.set_option("count_fragments", 1)
     ms = grp.render(M, sf)
     assert ms > 0.0
@@ -74,6 +75,15 @@ def test_group_frame_equals_one_context(native, mips, devices):
     grp.render(M, sf, [cut, 5], [2**62, 0], clear=False)           # "to the end" + an empty range
     grp.end_frame()
     assert close(grp.root.read_image()[..., 0], want[..., 0])
+    # ... and the accumulators stayed shard-local and unrounded: the two-block frame is the one-block frame of the group to the
+    # last bit of float32 accumulation order (same shards, same float64 partial sums, rounded once), on either collective
+    two_blocks = grp.root.read_image().copy()
+    grp.render(M, sf)
+    grp.end_frame()
+    one_block = grp.root.read_image()
+    assert np.abs(two_blocks[..., 0].astype(np.float64) - one_block[..., 0]).max() <= 2e-7 * one_block[..., 0].max()
+    with pytest.raises(native.BackendError, match="already reduced"):
+        grp.root.set_reduced_image(one_block)              # the presentation image is handed over once per frame
     # a block that touches only the last shard still clears the others
     grp.render(M, sf, [n - 1000], [1000], clear=True)
     grp.end_frame()
@@ -111,6 +121,32 @@ def test_group_uploads_and_errors(native, mips):
     assert np.abs(got[..., 1] - want[..., 1]).max() <= 1e-4 * scale          # signed quantity: cancelling sums, other order
     with pytest.raises(native.BackendError, match="negative length"):
         grp.render(M, sf, [0], [-5])
+    # a member touched behind the group's back (another channel layout) is refused on the calling thread, before any collective
+    grp.render(M, sf)
+    grp.member(1).set_reduced_image(np.zeros((R, R, 2), dtype=np.float32))
+    with pytest.raises(native.BackendError, match="context 1 was already reduced"):
+        grp.end_frame()
+    grp.close()
+    one.close()
+    # rgb through the group: band magnitudes cut per shard == the one-context contraction
+    mags = rs.uniform(2.0, 9.0, size=(3, n))
+    W = np.diag([0.5, 1.0, 1.0])
+    one = native.Context(R, 4)
+    one.set_kernel_mips(mips)
+    one.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, None)
+    one.upload_band_magnitudes(mags, W)
+    one.render(M, sf, mode=native.MODE_RGB)
+    want = one.read_image().astype(np.float64)
+    grp = native.Group(R, 4, [0, 0, 0])
+    grp.set_kernel_mips(mips)
+    grp.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, None)
+    grp.upload_band_magnitudes(mags, W)
+    grp.render(M, sf, mode=native.MODE_RGB)
+    grp.end_frame()
+    got = grp.root.read_image().astype(np.float64)
+    for c in range(3):
+        assert close(got[..., c], want[..., c])
+    assert np.array_equal(got[..., 3], want[..., 3])
     grp.close()
     one.close()
     with pytest.raises(native.BackendError):

@@ -111,6 +111,12 @@ class FakeContext:
     def write_image(self, img):
         self.image = np.ascontiguousarray(img, dtype=np.float32).copy()
 
+    def set_reduced_image(self, total):
+        # tsp_set_reduced_image: the caller's sum becomes the presentation copy, the accumulator stays this shard's
+        assert not getattr(self, "reduced", False), "already reduced"
+        self.presented = np.ascontiguousarray(total, dtype=np.float32).copy()
+        self.reduced = True
+
     def stats(self):
         return {"n_particles": 0, "ms_total": 1.0}
 

@@ -91,6 +91,7 @@ SIGNATURES = {
     "tsp_comm_init": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
     "tsp_comm_reduce_image": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "tsp_comm_destroy": (ctypes.c_int, [_ctx]),
+    "tsp_set_reduced_image": (ctypes.c_int, [_ctx, _fp]),
     # several GPUs behind one handle (C clients; the Python layer's own driver is multigpu.MultiGpuContext)
     "tsp_group_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.POINTER(_ctx)]),
     "tsp_group_destroy": (None, [_ctx]),
@@ -110,6 +111,8 @@ SIGNATURES = {
                                         ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "tsp_group_end_frame": (ctypes.c_int, [_ctx, ctypes.POINTER(ctypes.c_double)]),
     "tsp_group_get_stats": (ctypes.c_int, [_ctx, ctypes.POINTER(Stats)]),
+    "tsp_group_shard_range": (ctypes.c_int, [_ctx, ctypes.c_int, _i64p, _i64p]),
+    "tsp_group_upload_band_magnitudes": (ctypes.c_int, [_ctx, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None
@@ -426,6 +429,13 @@ class Context:
         if getattr(self, "_h", None):
             _check(self._lib.tsp_comm_destroy(self._h))
 
+    def set_reduced_image(self, total):
+        """Hand over a sum the caller formed (host collective): presentation image only, the accumulator stays this shard's."""
+        total = np.ascontiguousarray(total, dtype=np.float32)
+        if total.shape != (self.resolution, self.resolution, self.active_channels):
+            raise ValueError(f"image shape {total.shape} does not fit the render target")
+        _check(self._lib.tsp_set_reduced_image(self._h, _ptr(total)))
+
     def comm_reduce_image(self, root=0):
         ms = ctypes.c_double(0.0)
         _check(self._lib.tsp_comm_reduce_image(self._h, root, ctypes.byref(ms)))
@@ -494,6 +504,24 @@ class Group:
     def upload_quantity(self, q):
         qa = None if q is None else _f32(q, self.num_particles, "q")
         _check(self._lib.tsp_group_upload_quantity(self._g, None if qa is None else _ptr(qa)))
+
+    def upload_rgb(self, r, g, b):
+        n = self.num_particles
+        arrs = [_f32(a, n, nm) for a, nm in ((r, "r"), (g, "g"), (b, "b"))]
+        _check(self._lib.tsp_group_upload_rgb(self._g, *[_ptr(a) for a in arrs]))
+
+    def upload_band_magnitudes(self, mags, weights):
+        mags = np.ascontiguousarray(mags, dtype=np.float64)
+        weights = np.ascontiguousarray(weights, dtype=np.float64)
+        if mags.ndim != 2 or mags.shape[1] != self.num_particles or weights.shape != (3, mags.shape[0]):
+            raise ValueError("mags must be (n_bands, N) and weights (3, n_bands)")
+        dp = ctypes.POINTER(ctypes.c_double)
+        _check(self._lib.tsp_group_upload_band_magnitudes(self._g, mags.shape[0], mags.ctypes.data_as(dp), weights.ctypes.data_as(dp)))
+
+    def shard_range(self, index):
+        first, count = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(self._lib.tsp_group_shard_range(self._g, int(index), ctypes.byref(first), ctypes.byref(count)))
+        return first.value, count.value
 
     def generate_synthetic(self, n_total, first=0, count=None, seed=1337, h_cap=0.0, with_quantity=False, with_rgb=False):
         count = n_total - first if count is None else count

@@ -507,6 +507,17 @@ int tsp_write_image(tsp_context *ctx, const float *in) {
     return TSP_OK;
 }
 
+// The cross-shard SUM becomes this context's float32 presentation image (what read-back, colormap and autorange see); the
+// float64 accumulator keeps the context's own partial sums, as after an in-place RCCL reduce (tsp_comm_reduce_image)
+int tsp_set_reduced_image(tsp_context *ctx, const float *sum) {
+    TSP_REQUIRE(ctx && sum, TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(!ctx->image_is_reduced, TSP_ESTATE, "the render target was already reduced for this frame (call tsp_render before reducing again)");
+    TSP_HIP(hipSetDevice(ctx->device));
+    TSP_HIP(hipMemcpy(ctx->image, sum, (size_t)ctx->R * ctx->R * ctx->C * sizeof(float), hipMemcpyHostToDevice));
+    ctx->image_is_reduced = true;
+    return TSP_OK;
+}
+
 static int ensure_lut(tsp_context *ctx, const float *lut_rgba, int n_lut) {
     TSP_REQUIRE(lut_rgba && n_lut >= 2 && n_lut <= 65536, TSP_EINVAL, "bad colormap LUT (n=%d)", n_lut);
     if (ctx->lut_capacity < n_lut) {
@@ -730,16 +741,6 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         // 1 = auto; 2, 4-7 force a strip shape / occupancy of kernel H2 (A/B and tests)
         TSP_REQUIRE(value >= 1 && value <= 7 && value != 3, TSP_EINVAL, "huge_variant out of range");
         ctx->huge_variant = (int)value;
-        return TSP_OK;
-    }
-    if (!strcmp(name, "xcd_group_mid")) {
-        TSP_REQUIRE(value >= -1 && value <= 4096, TSP_EINVAL, "%s out of range", name);
-        ctx->xcd_group_mid = (int)value;
-        return TSP_OK;
-    }
-    if (!strcmp(name, "xcd_group")) {         // tiles per slice in the XCD-aware workgroup order of kernels M / H2 (0 = tile-major, as rounds 1-4)
-        TSP_REQUIRE(value >= 0 && value <= 4096, TSP_EINVAL, "%s out of range", name);
-        ctx->xcd_group = (int)value;
         return TSP_OK;
     }
     if (!strcmp(name, "reorder_interleave")) {   // read by the next tsp_reorder_spatial

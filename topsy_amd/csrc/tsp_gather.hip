@@ -74,8 +74,9 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int R = a.cam.R;
-    int tile_id, sp;
-    tile_and_split(blockIdx.x, a.split, a.n_tiles, a.xcd_group, tile_id, sp);
+    // (blockIdx = tile * split + sp: an XCD-aware order -- the workgroups resident on one XCD walking several tiles per slice of the
+    // record list, so that the list crosses the fabric once per tile group -- measured 7-11 % SLOWER at 1e9 particles: round 5)
+    const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
     const int tx0 = (tile_id % a.tiles_x) * TW, ty0 = (tile_id / a.tiles_x) * TH;
     for (int i = tid; i < PT_ROWS * PT_STRIDE; i += H2T) {
         const int j = min(i / PT_STRIDE, 63), x = min(i % PT_STRIDE, 63);
@@ -289,6 +290,9 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             // is straight-line (an uncovered row has fy = gy = 0); groups of four rows wholly outside the footprint are
             // skipped.  (Laying the change out of line as the unlikely path measured slower: this kernel serves the
             // footprints of 64 px and up, whose texel rows change every 1-8 pixel rows below 512 px.)
+            // (Round 5: a second, test-free copy of a group's eight FMAs for the groups without a texel-row change -- the per-row bit
+            // tests are three quarters of this kernel's scalar instructions -- made the register allocator spill around every
+            // footprint's set-up at the control-flow merges: 32.7 -> 49 ms at 1e9 particles.  One code path per row it stays.)
 #define TSP_H2_GROUP(K)                                                                                        \
             if constexpr ((K) < NG) {                                                                          \
                 if constexpr (JIT && (K) + 1 < NG) rowf[((K) + 1) & 1] = rt_quad[4 * ((K) + 1)];               \
@@ -360,7 +364,6 @@ static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
     split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
     ta.split = split;
     ta.tiles_x = htiles_x;
-    ta.n_tiles = htiles; ta.xcd_group = ctx->xcd_group;
     if (ta.count_frag) hipLaunchKernelGGL((splat_huge2_kernel<MODE, NACC, W, HR, OCC, true>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
     else hipLaunchKernelGGL((splat_huge2_kernel<MODE, NACC, W, HR, OCC, false>), dim3(htiles * split), dim3(H2T), smem, ctx->stream, ta);
     TSP_HIP(hipGetLastError());

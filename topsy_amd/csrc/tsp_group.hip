@@ -6,8 +6,8 @@
 // SplitBuffers._calculate_splits, src/topsy/split_buffers.py:26-38), a render block's (start, len) ranges are intersected
 // with every shard (global_to_split_monotonic, :78-116) and the G tsp_render calls run concurrently, one host thread per
 // context; a frame ends with tsp_group_end_frame = the ONE sum-reduce of the float32 image onto context 0 (RCCL over xGMI,
-// or -- when two contexts share a device, which RCCL refuses: single-GPU test boxes -- a read-back / add / write-back
-// through the host).  Everything that looks at the finished frame (tsp_read_image, tsp_colormap_*, tsp_content_*,
+// or -- when two contexts share a device, which RCCL refuses: single-GPU test boxes, or when librccl cannot be loaded -- a
+// read-back / add / write-back of the float32 presentation images through the host).  Everything that looks at the finished frame (tsp_read_image, tsp_colormap_*, tsp_content_*,
 // tsp_tile_periodic) is called on tsp_group_context(group, 0).  The Python layer's MultiGpuContext (topsy_amd/multigpu.py)
 // is the same choreography in Python (it also offers the block-cyclic assignment for cell-sorted loaders).
 #include <algorithm>
@@ -22,7 +22,6 @@ struct tsp_group {
     std::vector<int64_t> bounds;          // shard g owns global indices [bounds[g], bounds[g + 1])
     bool rccl = false;                    // distinct devices: RCCL; else the host collective
     bool needs_reduce = false;            // partial images were rendered since the last end_frame
-    std::vector<float> root_partial;      // host collective: the root's own partial image while its target holds the sum
     int R = 0, Ccap = 0;
 };
 
@@ -84,15 +83,24 @@ int tsp_group_create(int n_devices, const int *device_ids, int resolution, int n
     set_bounds(grp, 0);
     if (grp->rccl) {
         char uid[TSP_UNIQUE_ID_BYTES];
-        int rc = tsp_comm_unique_id(uid);
-        // ncclCommInitRank blocks until every rank has joined: all G calls at once
-        if (!rc) rc = for_each_context(grp, [&](int g) { return tsp_comm_init(grp->ctx[g], n_devices, g, uid); });
-        if (rc) {
-            const std::string keep = tsp_last_error();
-            for (tsp_context *p : grp->ctx) tsp_destroy(p);
-            delete grp;
-            set_error("%s", keep.c_str());
-            return rc;
+        if (tsp_comm_unique_id(uid) != TSP_OK) {
+            // RCCL cannot be loaded: the sum still exists -- through the host (what contexts that share a device always use)
+            grp->rccl = false;
+        } else {
+            // ncclCommInitRank blocks until every rank has joined: all G calls at once.  Whatever can fail BEFORE the collective
+            // (selecting the device: the tsp_create calls above already ran on each of them) has been checked on this thread, so
+            // no rank can drop out while the others wait inside the collective.
+            int rc = TSP_OK;
+            for (int g = 0; g < n_devices && !rc; ++g)
+                if (hipSetDevice(grp->ctx[g]->device) != hipSuccess) { set_error("cannot select device %d", grp->ctx[g]->device); rc = TSP_EHIP; }
+            if (!rc) rc = for_each_context(grp, [&](int g) { return tsp_comm_init(grp->ctx[g], n_devices, g, uid); });
+            if (rc) {
+                const std::string keep = tsp_last_error();
+                for (tsp_context *p : grp->ctx) tsp_destroy(p);       // (tsp_destroy tears down whatever communicator exists)
+                delete grp;
+                set_error("%s", keep.c_str());
+                return rc;
+            }
         }
     }
     *out = grp;
@@ -124,7 +132,6 @@ int tsp_group_upload_particles(tsp_group *grp, int64_t n, const float *x, const 
     TSP_REQUIRE(grp && x && y && z && h, TSP_EINVAL, "NULL argument");
     TSP_REQUIRE(n >= 0, TSP_EINVAL, "negative particle count");
     set_bounds(grp, n);
-    grp->root_partial.clear();
     return for_each_context(grp, [&](int g) {
         const int64_t a = grp->bounds[g], len = grp->bounds[g + 1] - a;
         return tsp_upload_particles(grp->ctx[g], len, x + a, y + a, z + a, h + a, mass ? mass + a : nullptr);
@@ -149,7 +156,6 @@ int tsp_group_generate_synthetic(tsp_group *grp, int64_t n_total, int64_t first,
     TSP_REQUIRE(grp, TSP_EINVAL, "NULL group");
     TSP_REQUIRE(count >= 0, TSP_EINVAL, "negative particle count");
     set_bounds(grp, count);
-    grp->root_partial.clear();
     return for_each_context(grp, [&](int g) {
         const int64_t a = grp->bounds[g], len = grp->bounds[g + 1] - a;
         return tsp_generate_synthetic(grp->ctx[g], n_total, first + a, len, seed, h_cap, with_quantity, with_rgb);
@@ -181,15 +187,6 @@ int tsp_group_render(tsp_group *grp, const float *M, float scale_factor, const i
     const int64_t all_start = 0, all_len = grp->bounds.back();
     if (!starts) { starts = &all_start; lens = &all_len; n_ranges = 1; }
     for (int i = 0; i < n_ranges; ++i) TSP_REQUIRE(lens[i] >= 0, TSP_EINVAL, "range %d has negative length %lld", i, (long long)lens[i]);
-    if (!grp->root_partial.empty()) {
-        // host collective: the root's target holds the SUM of the last frame; give it back its own partial frame before it
-        // accumulates (clear = 0) -- a cleared frame needs nothing restored
-        if (!clear) {
-            const int rc = tsp_write_image(grp->ctx[0], grp->root_partial.data());
-            if (rc) return rc;
-        }
-        grp->root_partial.clear();
-    }
     std::vector<double> ms(G, 0.0);
     const int rc = for_each_context(grp, [&](int g) {
         // clip the global ranges to shard g and re-base them; a shard the block does not touch still takes part with an
@@ -219,8 +216,17 @@ int tsp_group_end_frame(tsp_group *grp, double *ms_out) {
     TSP_REQUIRE(grp, TSP_EINVAL, "NULL group");
     if (ms_out) *ms_out = 0.0;
     if (!grp->needs_reduce || grp->ctx.size() == 1) { grp->needs_reduce = false; return TSP_OK; }
-    grp->needs_reduce = false;
     const int G = (int)grp->ctx.size();
+    // Every member's preconditions are checked HERE, on the calling thread: a rank that failed on its own thread after the
+    // others had entered the collective would leave them waiting in it for ever (a caller may have touched one member through
+    // tsp_group_context, e.g. rendered another mode on it or reduced it by hand)
+    for (int g = 0; g < G; ++g) {
+        const tsp_context *c = grp->ctx[g];
+        TSP_REQUIRE(c->C == grp->ctx[0]->C, TSP_ESTATE, "context %d holds a %d-channel image, context 0 a %d-channel one", g, c->C, grp->ctx[0]->C);
+        TSP_REQUIRE(!c->image_is_reduced, TSP_ESTATE, "context %d was already reduced for this frame", g);
+        TSP_REQUIRE(!grp->rccl || c->comm, TSP_ESTATE, "context %d has lost its communicator", g);
+    }
+    grp->needs_reduce = false;
     if (grp->rccl) {
         std::vector<double> ms(G, 0.0);
         const int rc = for_each_context(grp, [&](int g) { return tsp_comm_reduce_image(grp->ctx[g], 0, &ms[g]); });
@@ -228,18 +234,40 @@ int tsp_group_end_frame(tsp_group *grp, double *ms_out) {
         if (ms_out) *ms_out = *std::max_element(ms.begin(), ms.end());
         return TSP_OK;
     }
-    // contexts share a device: sum through the host (test boxes; float32 copy of the root's partial frame kept for REFINE)
+    // Host collective (contexts that share a device, which RCCL refuses -- single-GPU test boxes -- or no RCCL at all): the
+    // float32 partial images are read back, added in rank order and the sum becomes context 0's PRESENTATION image only, exactly
+    // what the RCCL reduce does in place: every float64 accumulator, the root's included, stays shard-local, so a later
+    // tsp_group_render with clear = 0 continues from unrounded partial sums (the REFINE contract of include/topsy_splat.h)
     const size_t count = (size_t)grp->R * grp->R * grp->ctx[0]->C;
     std::vector<std::vector<float>> part(G, std::vector<float>(count));
     int rc = for_each_context(grp, [&](int g) { return tsp_read_image(grp->ctx[g], part[g].data()); });
     if (rc) return rc;
-    std::vector<double> total(part[0].begin(), part[0].end());
+    std::vector<float> sum(part[0]);
     for (int g = 1; g < G; ++g)
-        for (size_t i = 0; i < count; ++i) total[i] += part[g][i];
-    grp->root_partial = part[0];
-    std::vector<float> sum(count);
-    for (size_t i = 0; i < count; ++i) sum[i] = (float)total[i];
-    return tsp_write_image(grp->ctx[0], sum.data());
+        for (size_t i = 0; i < count; ++i) sum[i] += part[g][i];         // float32, rank order: as ncclReduce(sum, float32)
+    return tsp_set_reduced_image(grp->ctx[0], sum.data());
+}
+
+int tsp_group_shard_range(tsp_group *grp, int index, int64_t *first_out, int64_t *count_out) {
+    TSP_REQUIRE(grp && first_out && count_out, TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(index >= 0 && index < (int)grp->ctx.size(), TSP_EINVAL, "shard %d of %d", index, (int)grp->ctx.size());
+    *first_out = grp->bounds[index];
+    *count_out = grp->bounds[index + 1] - grp->bounds[index];
+    return TSP_OK;
+}
+
+int tsp_group_upload_band_magnitudes(tsp_group *grp, int n_bands, const double *mags, const double *weights) {
+    TSP_REQUIRE(grp && mags && weights, TSP_EINVAL, "NULL argument");
+    TSP_REQUIRE(n_bands >= 1 && n_bands <= 64, TSP_EINVAL, "n_bands %d out of range", n_bands);
+    // mags is [n_bands][n] over the WHOLE snapshot: every shard takes its columns of every band
+    const int64_t n = grp->bounds.back();
+    return for_each_context(grp, [&](int g) {
+        const int64_t a = grp->bounds[g], len = grp->bounds[g + 1] - a;
+        if (len == 0) return (int)TSP_OK;
+        std::vector<double> cut((size_t)n_bands * len);
+        for (int k = 0; k < n_bands; ++k) std::copy(mags + (size_t)k * n + a, mags + (size_t)k * n + a + len, cut.begin() + (size_t)k * len);
+        return tsp_upload_band_magnitudes(grp->ctx[g], n_bands, cut.data(), weights);
+    });
 }
 
 int tsp_group_get_stats(tsp_group *grp, tsp_stats *out) {

@@ -138,8 +138,6 @@ struct tsp_context {
     double *int_tables = nullptr;     // kernel I: breakpoint strengths of the level-0 kernel image and their prefix sums (integrated_tables)
     int huge_variant = 1;             // kernel H2's strip shape / occupancy: 1 = auto (density: 64x32 strips at 8 waves/SIMD from 7e5 records, 64x16 below; two channels 64x16 at 7; rgb at 5), 2 / 4-7 = A/B builds
     int mid_split = 128, huge_split = 0, mega_split = 0;  // workgroups per image tile of kernels M / H2 / I (0 = auto)
-    int xcd_group_mid = -1;          // kernel M's own value of xcd_group (-1: follow xcd_group)
-    int xcd_group = 16;              // tile kernels: tiles an XCD walks per slice of the record list (tile_and_split(), tsp_pipeline.h); 0 = the tile-major order of rounds 1-4
     bool reorder_interleave = true;  // tsp_reorder_spatial transposes every 512-particle block 64 x 8 (lane decorrelation for kernel S, tsp_data.hip)
     int stream_blocks_per_cu = 100;  // kernel S grid bound: ~10 chunks per workgroup at 1e8 particles balances dense and sparse chunks
     bool chunk_cull = true;           // chunks (512 consecutive particles) whose bounds lie outside the view are skipped by kernel S

@@ -70,28 +70,10 @@ struct TileArgs {
     double *img;
     Counters *cnt;
     int tiles_x, split;
-    int n_tiles, xcd_group;   // workgroup -> (tile, split) mapping: see tile_and_split()
     int count_frag;
     float disc_k2;     // (0.5235)^2 when the LUT is zero outside the inscribed disc (exact corner culling), else 0
     float p_lo, p_hi;  // kernel H2 takes the records with p_lo <= P < p_hi
 };
-
-// Which (tile, slice of the record list) a workgroup of the tile kernels takes.  Blocks go to the eight XCDs round-robin
-// (block b runs on XCD b % 8: observed, used for speed only) and each XCD has its own 4 MiB L2.  With b = tile * split + sp
-// (rounds 1-4) slice sp is always read on XCD sp % 8, but by one tile at a time: every tile re-fetched the whole list through
-// the fabric (kernel H2 at 1e9 particles: 12.7 GB of reads per launch for an 85 MB list).  Here the slices keep their XCD
-// (sp % 8 == b % 8) and an XCD walks `xcd_group` tiles per slice before the next slice: the workgroups resident on an XCD at
-// one time read the same few slices -- one miss per line and XCD per tile group.  Tiles stay in row-major groups, so the
-// launch still ends on the light bottom rows.  xcd_group = 0 (or a split that is no multiple of 8): the old mapping.
-__device__ __forceinline__ void tile_and_split(unsigned b, int split, int n_tiles, int xcd_group, int &tile, int &sp) {
-    if (xcd_group <= 0 || (split & 7) != 0) { tile = (int)(b / (unsigned)split); sp = (int)(b % (unsigned)split); return; }
-    const unsigned x = b & 7u, q = b >> 3, s8 = (unsigned)split >> 3, per_group = (unsigned)xcd_group * s8;
-    const unsigned g = q / per_group, r = q - g * per_group;
-    const unsigned gsize = min((unsigned)xcd_group, (unsigned)n_tiles - g * (unsigned)xcd_group);
-    const unsigned si = r / gsize;
-    tile = (int)(g * (unsigned)xcd_group + (r - si * gsize));
-    sp = (int)(si * 8u + x);
-}
 
 // Kernel H2 (tsp_gather.hip) for the footprints >= 64 px of one render block: `huge_*` = the records below the option
 // integrated_px (all of them by default), `mega_*` = the records at least that wide, which kernel I draws.  Records ctx->ev[10]

@@ -94,6 +94,7 @@ struct StreamArgs {
     int n_ranges;
     int n_chunks;
     int chunks_per_block;
+    int min_chunks_per_block;  // chunk culling: the smallest share of surviving chunks a workgroup takes (see the kernel)
     Camera cam;
     const float *mips;
     double *img;
@@ -254,13 +255,21 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
     {
         CArgs *ap = KA();
         R = ap->cam.R;
+        // With chunk culling the launch is sized for ALL chunks and the workgroups share out the survivors, whose number only
+        // the device knows: an even share per workgroup (not the first alive / chunks_per_block workgroups at the unculled
+        // share: a strongly zoomed view would run on a handful of them), but never fewer than min_chunks_per_block consecutive
+        // chunks (window set-up and final flush are paid per workgroup).  A workgroup without a share leaves before it touches LDS.
+        int per = ap->chunks_per_block, n_todo = ap->n_chunks;
+        if (ap->alive) {
+            n_todo = (int)ap->cull_info[0];
+            per = min(per, max(ap->min_chunks_per_block, (n_todo + (int)gridDim.x - 1) / (int)gridDim.x));
+        }
+        c_begin = blockIdx.x * per;
+        c_end = min(c_begin + per, n_todo);
+        if (c_begin >= c_end) return;
         const float *mips = ap->mips;
         for (int i = tid; i < WC * WIN * WIN; i += SBLOCK) win[i] = 0.0;
         for (int i = tid; i < 320; i += SBLOCK) T23[i] = mips[5120 + i];
-        c_begin = blockIdx.x * ap->chunks_per_block;
-        // with chunk culling the workgroups share out the surviving chunks (the launch is sized for all of them: the surplus exits)
-        const int n_todo = ap->alive ? (int)ap->cull_info[0] : ap->n_chunks;
-        c_end = min(c_begin + ap->chunks_per_block, n_todo);
     }
     __syncthreads();
 
@@ -710,6 +719,9 @@ constexpr int MT = 512;              // threads per workgroup of kernel M (8 wav
 // quadrant of each level in LDS -- 5.4 KB instead of 21.8 KB -- where that raises the occupancy (rgb), and folds a texel index once per row / column block: i -> min(i, n - 1 - i).
 constexpr int MIPQ_TOTAL = 1024 + 256 + 64 + 16;
 __device__ __forceinline__ int mipq_offset(int lvl) { return lvl == 0 ? 0 : (lvl == 1 ? 1024 : (lvl == 2 ? 1280 : 1344)); }
+// (Round 5 re-measured padded table rows -- a row stride of 8 * odd floats, so that the 8 x 8 lanes of a step read 64 distinct
+// banks -- at 1e9 particles: kernel M 16.4 ms with and without.  The 30 % bank conflicts of its LUT reads are not on its critical
+// path; the natural layout stays.)
 
 // WC = channels accumulated in the LDS tile (1 for a density-only render, else the image's channel count);
 // QUAD = the LUT is mirror-symmetric: quadrant tables
@@ -726,8 +738,7 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
     __shared__ int s_wcnt[MT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int R = a.cam.R;
-    int tile_id, sp;
-    tile_and_split(blockIdx.x, a.split, a.n_tiles, a.xcd_group, tile_id, sp);
+    const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
     const int tx0 = (tile_id % a.tiles_x) * TILE, ty0 = (tile_id / a.tiles_x) * MTILE_H;
     const float fx0 = (float)tx0, fy0 = (float)ty0, fx1 = (float)(tx0 + TILE), fy1 = (float)(ty0 + MTILE_H);
     if (QUAD) {
@@ -1091,6 +1102,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     const bool cull = ctx->chunk_cull && n_chunks >= 4096;
     unsigned long long cull_info_h[2] = {0, 0};
     ctx->chunk_culled_particles = 0;
+    TSP_HIP(hipEventRecord(ctx->ev[7], st));      // (the culling passes, and the block bounds when they are stale, count as kernel S's time)
     if (cull) {
         if ((rc = ensure_block_bounds(ctx))) return rc;
         if (!ws.cull_info) TSP_HIP(hipMalloc((void **)&ws.cull_info, 2 * sizeof(unsigned long long)));
@@ -1119,6 +1131,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         // particles is 196 chunks)
         const int min_cpb = std::max(1, std::min(8, n_chunks / (ctx->cu_count * 2)));
         sa.chunks_per_block = std::max(min_cpb, (n_chunks + max_blocks - 1) / max_blocks);
+        sa.min_chunks_per_block = min_cpb;
         const int grid_s = (n_chunks + sa.chunks_per_block - 1) / sa.chunks_per_block;
         sa.cam = cam; sa.mips = ctx->mips; sa.img = ctx->image64;
         sa.mid_geom = (float4 *)ws.mid_geom; sa.mid_w = (float *)ws.mid_w; sa.mid_capacity = ws.mid_capacity;
@@ -1188,8 +1201,6 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         // a small render block (an interactive frame's first 1e5 particles leave ~3e4 records) does not need 65 536
         // workgroups that each load the LUT: fewer splits in proportion below 2^18 records
         if ((long long)hc.n_mid < (1ll << 18)) ta.split = std::max(4, (int)((long long)ta.split * (long long)hc.n_mid >> 18));
-        // (one tile row = the tiles that share a band's chunk list: the XCD-aware order walks a row per slice)
-        ta.n_tiles = tiles_x * mtiles_y; ta.xcd_group = ctx->xcd_group_mid >= 0 ? ctx->xcd_group_mid : (ctx->xcd_group > 0 ? tiles_x : 0);
         const dim3 grid_m(tiles_x * mtiles_y * ta.split);
         if (WCr == 1 && quad) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1, true>), grid_m, dim3(MT), smem_m, st_mid, ta);
         else if (WCr == 1) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1, false>), grid_m, dim3(MT), smem_m, st_mid, ta);
@@ -1212,7 +1223,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     if (ctx->overlap_mid_huge) TSP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));     // join: later work on `st` sees both
     TSP_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
-    TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.ms_stream = ms;
+    TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[cull ? 7 : 2], ctx->ev[3])); ctx->stats.ms_stream = ms;
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->stats.ms_mid = ms;
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10])); ctx->stats.ms_huge = ms;
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[10], ctx->ev[11])); ctx->stats.ms_mega = ms;

@@ -57,7 +57,6 @@ class MultiGpuContext:
         self._pool = ThreadPoolExecutor(max_workers=len(device_ids), thread_name_prefix="tsp-gpu")
         self._bounds = np.zeros(len(device_ids) + 1, dtype=np.int64)
         self._needs_reduce = False          # the shards hold partial images that have not been summed onto the root yet
-        self._root_partial = None           # host collective: the root's own partial image while it holds the sum
         self.last_reduce_ms = 0.0
         # RCCL needs one device per rank; contexts that share a device (single-GPU boxes, tests) sum through the host
         self.collective = "rccl" if len(set(device_ids)) == len(device_ids) else "host"
@@ -269,13 +268,6 @@ class MultiGpuContext:
             starts, lens = [0], [self.num_particles]
         starts = np.asarray(starts, dtype=np.int64)
         lens = np.asarray(lens, dtype=np.int64)
-        if self._root_partial is not None:
-            # host collective: the root's image currently holds the SUM; give it back its own partial frame before it
-            # accumulates (clear = False) -- a cleared frame needs nothing restored
-            if not clear:
-                self.contexts[0].write_image(self._root_partial)
-            self._root_partial = None
-
         def go(g, c):
             s, l = self._local_ranges(starts, lens, g)
             if len(s) == 0:
@@ -296,12 +288,14 @@ class MultiGpuContext:
         else:
             import time
             t = time.perf_counter()
+            # host collective: the float32 partial images added in rank order (what ncclReduce(sum, float32) computes up to
+            # association); the sum becomes the root's PRESENTATION image only -- its float64 accumulator keeps its own
+            # partial sums, as after the in-place RCCL reduce, so REFINE blocks continue unrounded
             parts = self._map(lambda g, c: c.read_image())
-            self._root_partial = parts[0]
-            total = parts[0].astype(np.float64)
+            total = parts[0].copy()
             for p in parts[1:]:
                 total += p
-            self.contexts[0].write_image(total.astype(np.float32))
+            self.contexts[0].set_reduced_image(total)
             self.last_reduce_ms = (time.perf_counter() - t) * 1e3
         return self.last_reduce_ms
 
