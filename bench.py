@@ -26,7 +26,7 @@ can be imported).  At N = 1 the line also carries driver-timed extras: `shards_o
 the snapshot, one after another on this GPU: per-shard frame, max / mean, and the projected 1 -> 8 speed-up), the product
 path through the Visualizer (`visualizer_export_frame`, `interactive_frame`), BASELINE configs[1] (1e7 weighted), configs[2]
 (exactly 1e8), configs[4] (5e7 rgb, 2048^2), a stand-alone 1.25e8-particle snapshot (the headline of rounds 1-3), its
-h-capped bandwidth regime and the option integrated_px.  At N > 1 the line is self-validating: before timing a
+h-capped bandwidth regime.  At N > 1 the line is self-validating: before timing a
 rank-dependent constant image is reduced and checked (`reduce_selftest`), after timing the reduced frame is compared with
 the same snapshot rendered whole on rank 0's GPU (`reduce_check`); a failure exits non-zero.
 
@@ -47,11 +47,11 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_COPY_GBPS = 6290.0 # MI355X_MICROARCH.md: 6.29 TB/s measured (float4 copy)
 VALU_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32 vector peak (256 CUs x 4 SIMDs x 64 lanes x 2 flop x 2.4 GHz)
-# canonical arithmetic of one fragment: bilinear (P >= 64 px: kernel H2; kernel I as an option) acc += gy*top + fy*bot
+# canonical arithmetic of one fragment: bilinear (P >= 64 px: kernel H2) acc += gy*top + fy*bot
 # = 2 FMAs once the x-interpolated texel rows exist; nearest (kernels S / M) one multiply-add of the texel into the pixel
-FMAS_PER_FRAGMENT = {"stream": 1, "mid": 1, "huge": 2, "mega": 2}
+FMAS_PER_FRAGMENT = {"stream": 1, "mid": 1, "huge": 2}
 B_ALG = {"density": 20, "weighted": 24, "rgb": 28}     # algorithmic bytes/particle
-KERNELS = ("stream", "mid", "huge", "mega")        # tsp_stats names: kernels S, M, H2 and (option integrated_px only) I
+KERNELS = ("stream", "mid", "huge")        # tsp_stats names of kernels S, M, H2
 KERNEL_SYMBOL = {"stream": "splat_stream_kernel", "mid": "splat_mid_kernel", "huge": "splat_huge2_kernel"}
 # one ncclReduce of the R^2 x C float32 image onto the root over xGMI (ring: 7 steps of 1/8 of the image per link, ~153 GB/s per
 # link and ~20 us per step): an ESTIMATE -- no multi-GPU box was available to this build -- used only by `projected_speedup_1to8`
@@ -76,13 +76,14 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--generic", action="store_true", help="use the generic (global-atomic) kernel")
     ap.add_argument("--no-reorder", action="store_true")
-    ap.add_argument("--integrated-px", type=int, default=0,
-                    help="option integrated_px of the library (kernel I for footprints at least this wide); 0 = the default path")
     ap.add_argument("--shared-device-dry-run", action="store_true",
                     help="harness test on a 1-GPU box: every rank uses device 0 and the image reduce is skipped (RCCL refuses two "
                          "ranks on one device) -- the shard images are summed on the host instead, through the same self-test and "
                          "reduce_check -- so the launcher logic of an N > 1 run (rendezvous, shards, barriers, the max-over-ranks "
                          "time, the checks, the JSON line) can be exercised; the line is marked and its value means nothing")
+    ap.add_argument("--as-shard", default="",
+                    help="G:g -- profiling aid at N = 1: this GPU holds and renders only the index-range shard g of G of the snapshot "
+                         "(what rank g of a G-GPU run does, without the reduce); the line is marked and is not the headline")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline frames: no extra configurations, no CPU baseline (what the profiler runs, so "
                          "that every kernel instance in a profile belongs to the headline workload)")
@@ -197,6 +198,9 @@ def main():
     else:
         n_total = int(args.total_particles)
         first, n_per = shard_range(n_total, world, rank)
+        if args.as_shard and world == 1:
+            G, g = (int(v) for v in args.as_shard.split(":"))
+            first, n_per = shard_range(n_total, G, g)
     mode = {"density": _native.MODE_WEIGHTED, "weighted": _native.MODE_WEIGHTED, "rgb": _native.MODE_RGB}[args.mode]
     channels = 4 if args.mode == "rgb" else 2
     mips = kernel_lut.kernel_mips()
@@ -206,8 +210,6 @@ def main():
         local_rank = 0
     ctx = make_context(_native, mips, R, channels, local_rank, n_total, first, n_per, args, h_cap, args.mode)
     t_setup = time.time() - t_setup
-    if args.integrated_px:
-        ctx.set_option("integrated_px", args.integrated_px)
 
     use_comm = world > 1 and not args.shared_device_dry_run
     if use_comm:
@@ -305,7 +307,6 @@ def main():
                      f"(scale {args.scale:g}), reference TestDataLoader h-law, "
                      + (f"index-range sharded x{world} ({n_per:.4g}/GPU)" if world > 1 else "whole snapshot resident on one GPU")
                      + (f", h capped at {args.h_cap_px:g} px" if args.h_cap_px > 0 else "")
-                     + (f", option integrated_px = {args.integrated_px}" if args.integrated_px else "")
                      + ", splat + " + ("RCCL image reduce + " if world > 1 else "") + "colormap")
     measured_peak = ctx.measure_read_bandwidth(4 << 30, 5)
     prof = None
@@ -332,6 +333,9 @@ def main():
         "kernel_ms": means,
         "setup_s": t_setup,
     }
+    if args.as_shard and world == 1:
+        result["as_shard"] = (f"only the index range [{first}, {first + n_per}) of the snapshot is resident and rendered (shard {args.as_shard}): "
+                              "`value` counts the whole snapshot's particles and is NOT a measurement of it")
     if args.shared_device_dry_run:
         result["dry_run"] = ("ranks shared device 0 and the shard images were summed on the host instead of by RCCL: harness test "
                              "only, `value` is not a measurement")
@@ -358,7 +362,7 @@ def main():
             result["speedup_vs_1gpu_same_snapshot"] = None
             result["reduce_check"] = {"ok": False, "error": "the whole snapshot could not be rendered on rank 0: " + str(e)[:160], "ranks": world}
             ok = False
-    extras = world == 1 and not args.generic and not args.headline_only and args.h_cap_px <= 0 and not args.integrated_px
+    extras = world == 1 and not args.generic and not args.headline_only and args.h_cap_px <= 0 and not args.as_shard
     if extras and args.mode == "density":
         whole_ms = ms_per_step
         if ctx is not None:
@@ -374,7 +378,6 @@ def main():
         result["standalone_1p25e8"] = config_line(ctx, n_sh, "density", R, args, "a stand-alone 1.25e8-particle snapshot (the headline "
                                                   "of rounds 1-3; h-law of N = 1.25e8, wider footprints than a shard of the 1e9 snapshot)",
                                                   regenerate=False)
-        result["integrated_option"] = integrated_line(ctx, M, sf, mode, n_sh)
         result["bandwidth_regime"] = hcapped_line(args, ctx, n_sh, n_sh, 0, M, sf, mode, measured_peak)
         # the other single-GPU configurations of BASELINE.json, driver-timed beside the headline (never `value`)
         result["baseline_config_1"] = config_line(ctx, 10_000_000, "weighted", R, args,
@@ -391,7 +394,7 @@ def main():
         # the product path: the same frames through the Visualizer / SPH / ColormapHolder surface (reference visualizer.py, sph.py:306-332)
         result["visualizer_export_frame"] = visualizer_lines(local_rank, R, args, whole_ms, n_total if (n_total == 10**9 and not weak) else None)
         result["interactive_frame"] = interactive_line(local_rank, R, args)
-    if not args.no_cpu_baseline and not args.headline_only and world == 1:      # reported baseline: rank 0 at N = 1 only
+    if not args.no_cpu_baseline and not args.headline_only and world == 1 and not args.as_shard:      # reported baseline: rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(args, n_total, M, sf, R)
     print(json.dumps(result), flush=True)
     if dist is not None:
@@ -559,7 +562,7 @@ def shards_line(_native, mips, R, device, n_total, G, args, mode, lut, vmin, vma
             cmap_ms = float(np.median(ts))
         st = ctx.stats()
         per.append({"shard": g, "first": first, "particles": cnt, "ms_per_step": float(np.median(ms)),
-                    "kernel_ms": {k: float(np.median(v)) for k, v in kms.items() if k != "mega"},
+                    "kernel_ms": {k: float(np.median(v)) for k, v in kms.items()},
                     "records": {"small": int(st["n_small"]), "mid": int(st["n_mid"]), "huge": int(st["n_huge"]), "culled": int(st["n_culled"])}})
     ctx.close()
     t = [x["ms_per_step"] for x in per]
@@ -653,27 +656,6 @@ def interactive_line(device, R, args, n=1_000_000_000, frames=24):
                 "refine_frames_to_complete": refine, "refine_ms_to_complete": refine_ms}
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"[:240]}
-
-
-def integrated_line(ctx, M, sf, mode, n_per, px=256, frames=10):
-    ctx.render(M, sf, clear=True, mode=mode)
-    exact = ctx.read_image()[..., 0].astype(np.float64)
-    ctx.set_option("integrated_px", px)
-    ms, mega = [], []
-    for i in range(frames + 1):
-        t = ctx.render(M, sf, clear=True, mode=mode)
-        if i:
-            ms.append(t); mega.append(ctx.stats()["ms_mega"])
-    st = ctx.stats()
-    fast = ctx.read_image()[..., 0].astype(np.float64)
-    ctx.set_option("integrated_px", 0)
-    lit = exact > 0
-    rel = np.abs(fast - exact)[lit] / exact[lit]
-    return {"workload": f"the headline snapshot with the option integrated_px = {px} (footprints >= {px} px through kernel I)",
-            "ms_per_step": float(np.median(ms)), "value": n_per / (float(np.median(ms)) * 1e-3), "unit": "particles/s",
-            "kernel_I_ms": float(np.median(mega)), "records_through_kernel_I": int(st["n_mega"]),
-            "max_relative_difference_per_pixel_from_the_exact_kernels": float(rel.max()) if rel.size else 0.0,
-            "pixels_compared": int(lit.sum())}
 
 
 def hcapped_line(args, ctx, n_total, n_per, rank, M, sf, mode, measured_peak, cap_px=8.0, frames=10):

@@ -69,8 +69,10 @@ const char *tsp_last_error(void);
  * 103: tsp_stats grew by 8 bytes (n_chunk_culled appended); same rule.  Defaults changed without an ABI change: kernel H3
  * (matrix cores) is an option ("p_mega_px" / "p_mega2_px" default to 0), chunk culling ("chunk_cull") is on.
  * 104: the matrix-core kernels and the round-1 gather kernel are gone (no default rule selected them): the options
- * "p_mega_px", "p_mega2_px", "p_mega_rgb_px", "mega_variant", "rgb_mega_variant" and "huge_variant" = 0 / 3 now return
- * TSP_EINVAL; tsp_stats keeps its layout (ms_mega / n_mega / n_fragments_mega now describe kernel I only). */
+ * "p_mega_px", "p_mega2_px", "p_mega_rgb_px", "mega_variant", "rgb_mega_variant", "mega_split", "integrated_px" (kernel I, the
+ * inexact option of round 3) and "huge_variant" = 0 / 3 now return TSP_EINVAL; tsp_stats keeps its layout (ms_mega, n_mega and
+ * n_fragments_mega are reserved: always 0).  New entry points: tsp_set_reduced_image, tsp_group_shard_range,
+ * tsp_group_upload_band_magnitudes. */
 int tsp_version(void);
 int tsp_stats_size(void);
 
@@ -223,28 +225,24 @@ typedef struct {
     int64_t n_particles;   /* particles visited (sum of range lengths) */
     int64_t n_small;       /* splatted by the streaming kernel */
     int64_t n_mid;         /* nearest-mip footprints deferred to the tile-scatter kernel */
-    int64_t n_huge;        /* bilinear footprints (P >= 64 px) deferred to the tile-gather kernels (incl. n_mega) */
+    int64_t n_huge;        /* bilinear footprints (P >= 64 px) deferred to the tile-gather kernel */
     int64_t n_culled;      /* z-slab / off-screen / non-finite */
     int64_t n_fragments;   /* pixel updates (only counted when TSP_STATS is enabled) */
     double ms_stream, ms_mid, ms_huge, ms_total; /* per-kernel GPU time, hipEvents; ms_huge = kernel H2 */
-    double ms_mega;        /* kernel I (option integrated_px: footprints at least that wide); 0 when it did not run */
-    int64_t n_mega;        /* footprints handled by kernel I */
+    double ms_mega;        /* reserved (0): a second gather kernel existed in rounds 2-4 */
+    int64_t n_mega;        /* reserved (0) */
     /* n_fragments by the kernel that drew them (counted like n_fragments; 0 on the generic pipeline): kernel S, kernel M,
-     * kernel H2, kernel I -- what bench.py prices each kernel's fragment-rate roofline with */
+     * kernel H2, reserved (0) -- what bench.py prices each kernel's fragment-rate roofline with */
     int64_t n_fragments_stream, n_fragments_mid, n_fragments_huge, n_fragments_mega;
     /* of n_culled: particles of chunks (512 consecutive particles) whose bounding box lay outside the view -- never read
      * (option "chunk_cull", on by default; needs >= 4096 chunks in the call, pays after tsp_reorder_spatial) */
     int64_t n_chunk_culled;
 } tsp_stats;
 int tsp_get_stats(tsp_context *ctx, tsp_stats *out);
-/* Options by name.  "count_fragments" (0/1): fragment counting (adds atomics; off by default).  "integrated_px" (0 = off, the
- * default, or >= 128): footprints at least this many pixels wide are drawn by kernel I -- the sparse second differences of
- * the bilinear footprint scattered and the image integrated twice along either axis -- instead of pixel by pixel; exact to
- * ~1e-6 of a footprint's PEAK value rather than of every pixel's own value (tests/test_gpu_integrated.py); a pixel whose
- * integrated value is below 1e-8 of the render block's largest peak contribution is written as exact 0 (decided on the density
- * channel for the two-channel modes, on any colour channel for rgb), so footprints more than 1e8 fainter than the block's
- * heaviest one are invisible where they lie alone, and the threshold is per render block.  The remaining
- * names are tuning and measurement aids of the pipeline (class boundaries, workgroup counts; csrc/tsp_api.hip). */
+/* Options by name.  "count_fragments" (0/1): fragment counting (adds atomics; off by default).  "use_quantity" (0/1): render
+ * density-only without dropping the resident quantity.  "chunk_cull" (1/0), "reorder_interleave" (1/0, read by the next
+ * tsp_reorder_spatial).  The remaining names are tuning and measurement aids of the pipeline ("p_small_milli", "mid_split",
+ * "huge_split", "huge_variant", "stream_blocks_per_cu", "overlap_mid_huge", "debug_*"; csrc/tsp_api.hip). */
 int tsp_set_option(tsp_context *ctx, const char *name, int64_t value);
 
 /* Streaming-read microbenchmark (float4 read-sum over `bytes` of device memory; best of a few launch shapes): returns GB/s.

@@ -23,13 +23,13 @@ def test_shard_ranges_partition_the_snapshot():
 
 
 def test_fragment_roofline_arithmetic():
-    frags = {"stream": 1e10, "mid": 2e10, "huge": 1e11, "mega": 1.5e11}
-    ms = {"stream": 10.0, "mid": 20.0, "huge": 25.0, "mega": 15.0}
+    frags = {"stream": 1e10, "mid": 2e10, "huge": 2.5e11}
+    ms = {"stream": 10.0, "mid": 20.0, "huge": 40.0}
     r = bench.fragment_roofline(frags, ms, 70.0)
-    flop = (1e10 + 2e10) * 1 * 2 + (1e11 + 1.5e11) * 2 * 2
+    flop = (1e10 + 2e10) * 1 * 2 + 2.5e11 * 2 * 2
     assert np.isclose(r["flop_per_frame"], flop)
     assert np.isclose(r["achieved"], flop / 70e-3 / 1e12) and np.isclose(r["frac"], r["achieved"] / bench.VALU_F32_PEAK_TFLOPS)
-    assert np.isclose(r["per_kernel"]["mega"]["achieved"], 1.5e11 * 4 / 15e-3 / 1e12)
+    assert np.isclose(r["per_kernel"]["huge"]["achieved"], 2.5e11 * 4 / 40e-3 / 1e12)
     assert r["per_kernel"]["stream"]["fmas_per_fragment"] == 1 and r["per_kernel"]["huge"]["fmas_per_fragment"] == 2
     zero = bench.fragment_roofline({}, {}, 0.0)
     assert zero["achieved"] == 0.0 and zero["per_kernel"]["mid"]["fragments"] == 0

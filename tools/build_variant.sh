@@ -7,7 +7,7 @@ ROOT=$(cd $(dirname $0)/.. && pwd)
 B=$ROOT/topsy_amd/csrc/build_$SUF
 mkdir -p $B
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function -I$ROOT/include $@"
-for f in tsp_api tsp_splat_generic tsp_pipeline tsp_gather tsp_integrated tsp_colormap tsp_postpass tsp_data tsp_comm tsp_group; do
+for f in tsp_api tsp_splat_generic tsp_pipeline tsp_gather tsp_colormap tsp_postpass tsp_data tsp_comm tsp_group; do
   /opt/rocm/bin/hipcc $FLAGS -c $ROOT/topsy_amd/csrc/$f.hip -o $B/$f.o &
 done
 wait

@@ -52,19 +52,16 @@ def counters(dirs):
 
 stats("trace", f"profiles/{tag}_bench_kernel_stats.csv")
 stats("hcap_trace", f"profiles/{tag}_hcapped_kernel_stats.csv")
-stats("shard_trace", f"profiles/{tag}_shard1p25e8_kernel_stats.csv")
-stats("mfma_trace", f"profiles/{tag}_mfma_option_kernel_stats.csv")
+stats("shard_trace", f"profiles/{tag}_shard3of8_kernel_stats.csv")
 out = {"command": "python3 bench.py --headline-only under rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum "
                   "TCC_MISS_sum / --pmc SQ_INSTS_* / --pmc SQ_LDS_* SQ_WAIT_* (separate passes); `hcapped` = the same with --particles-per-gpu 1.25e8 "
-                  "--h-cap-px 8; `shard1p25e8` = with --particles-per-gpu 1.25e8 (the headline workload of rounds 1-3)",
+                  "--h-cap-px 8; `shard3of8` = with --as-shard 8:3 (the index range [3.75e8, 5e8) of the 1e9 snapshot: what one of 8 GPUs renders)",
        "note": "FETCH_SIZE/WRITE_SIZE in KiB per dispatch; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads: "
                "HBM read bytes ~= 2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md, HBM section).  Every value is the mean over the launches of "
                "the pass; all launches belong to the headline workload (--headline-only)",
        "per_kernel": counters(("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds")),
        "hcapped_per_kernel": counters(("hcap_pmc_fetch", "hcap_pmc_lds")),
-       "shard1p25e8_per_kernel": counters(("shard_pmc_fetch", "shard_pmc_write", "shard_pmc_sq")),
-       # the headline snapshot with --p-mega-px 768 (kernel H3 drawing the footprints >= 768 px: the default of round 4, an option since)
-       "mfma_option_per_kernel": counters(("mfma_pmc_sq",))}
+       "shard3of8_per_kernel": counters(("shard_pmc_fetch", "shard_pmc_write", "shard_pmc_sq"))}
 try:
     out["bench_line"] = json.loads(open(f"{src}/bench.json").read().strip().splitlines()[-1])
 except Exception as ex:

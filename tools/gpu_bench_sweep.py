@@ -21,8 +21,8 @@ M = np.eye(4, dtype=np.float32); M[:3, :3] /= scale; M[2, :] = [0, 0, 0.5 / scal
 md = _native.MODE_RGB if mode == "rgb" else _native.MODE_WEIGHTED
 for f in range(frames):
     ms = ctx.render(M, 1.0 / scale, mode=md); st = ctx.stats()
-    print(f"frame {f}: total {ms:.3f} ms  S {st['ms_stream']:.3f}  M {st['ms_mid']:.3f}  H2 {st['ms_huge']:.3f}  H3 {st['ms_mega']:.3f}  small/mid/huge(mega)/cull {st['n_small']}/{st['n_mid']}/{st['n_huge']}({st['n_mega']})/{st['n_culled']}")
+    print(f"frame {f}: total {ms:.3f} ms  S {st['ms_stream']:.3f}  M {st['ms_mid']:.3f}  H2 {st['ms_huge']:.3f}  small/mid/huge/cull {st['n_small']}/{st['n_mid']}/{st['n_huge']}/{st['n_culled']}")
 ctx.set_option("count_fragments", 1); ctx.render(M, 1.0 / scale, mode=md); st = ctx.stats()
 print(f"fragments {st['n_fragments']:.4g} ({st['n_fragments']/n:.1f}/particle)  -> {n/ms*1e3:.3g} particles/s, {st['n_fragments']/ms*1e3:.3g} frags/s; stream GB/s {20*n/st['ms_stream']/1e6:.0f}")
-print("fragments by kernel S / M / H2 / H3:", st["n_fragments_stream"], st["n_fragments_mid"], st["n_fragments_huge"], st["n_fragments_mega"])
+print("fragments by kernel S / M / H2:", st["n_fragments_stream"], st["n_fragments_mid"], st["n_fragments_huge"])
 img = ctx.read_image(); print("mass sum", img[..., 0].sum() * (2*scale/R)**2, "expected ~", n * 1e-8)

@@ -17,5 +17,5 @@ for R, n, seed in [(2048, 3000, 1), (4096, 1500, 2), (3000, 2000, 3), (8192, 400
     ctx.render(M, sf); got = ctx.read_image(); st = ctx.stats()
     want, nfrag = oracle_c.splat(x, y, z, h, m, q, None, mode=0, M=M, sf=sf, R=R, mips=mips)
     rel = np.abs(got[..., 0].astype(np.float64) - want[..., 0]) / np.maximum(want[..., 0], 1e-300)
-    print(f"R={R} n={n}: frags {st['n_fragments']} vs {nfrag} ({'OK' if st['n_fragments']==nfrag else 'MISMATCH'}), huge/mega {st['n_huge']}/{st['n_mega']}, max rel err ch0 {rel[want[...,0]>0].max():.2e}")
+    print(f"R={R} n={n}: frags {st['n_fragments']} vs {nfrag} ({'OK' if st['n_fragments']==nfrag else 'MISMATCH'}), huge {st['n_huge']}, max rel err ch0 {rel[want[...,0]>0].max():.2e}")
     ctx.close()

@@ -4,7 +4,7 @@ import numpy as np
 from oracle import oracle_np, oracle_c
 from topsy_amd import _native as native, kernel_lut
 mips = kernel_lut.kernel_mips()
-# TSP_FUZZ_OPTS="huge_variant=7 mega_variant=1": library options forced on every context (kernel variants the record counts of
+# TSP_FUZZ_OPTS="huge_variant=7": library options forced on every context (kernel variants the record counts of
 # these small scenes would not select)
 OPTS = [kv.split("=") for kv in os.environ.get("TSP_FUZZ_OPTS", "").split()]
 def make_ctx(R, C):

@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$NAME
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 P="--headline-only --steps 3 --warmup 1 $@"
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $OUT/pmc_sq -o run -- python3 bench.py $P > $OUT/pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES -d $OUT/pmc_sq -o run -- python3 bench.py $P > $OUT/pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/pmc_lds -o run -- python3 bench.py $P > $OUT/pmc_lds.log 2>&1
 python3 - <<PY
 import csv, collections, glob

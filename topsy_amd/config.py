@@ -19,9 +19,12 @@ DEFAULT_CELLS_NSIDE = 16             # config.py:27
 CELL_LAYOUT_FRACTIONAL_PADDING = 1e-5  # config.py:33
 
 # --- backend-specific knobs (no reference counterpart) -------------------------------------
-# number of uniform random strata used by the load-time spatial ordering (tsp_reorder_spatial):
-# index prefixes stay unbiased samples at 1/STRATA granularity while runs stay screen-coherent.
-SPATIAL_ORDER_STRATA = 32
+# smallest number of uniform random strata used by the load-time spatial ordering (tsp_reorder_spatial):
+# index prefixes stay unbiased samples at 1/STRATA granularity while runs stay screen-coherent.  Fewer strata = denser strata =
+# more compact 512-particle chunks on screen (round 5, 32 -> 8: one shard of the 1e9 snapshot 10.15 -> 9.78 ms, exactly 1e8
+# particles 18.10 -> 17.94, 1.25e8 20.3 -> 19.9; <= 1e7 particles unchanged); a stratum of 1/8 of a <= 2.5e8-particle snapshot
+# still renders in 1-3 ms, well inside the 1/30 s budget of the progressive renderer, whose smallest block it is.
+SPATIAL_ORDER_STRATA = 8
 # large snapshots get more strata so that a stratum -- the smallest spatially unbiased block of the progressive
 # renderer -- holds at most about this many particles: 3.2e7 particles render in ~6 ms on an MI355X, well inside the
 # 1/30 s frame budget.  Fewer, larger strata keep 512-particle chunks more local on screen: the 1e9-particle snapshot in
@@ -29,11 +32,6 @@ SPATIAL_ORDER_STRATA = 32
 # kernel S 1.2 ms (more same-pixel collisions in its LDS window)
 MAX_PARTICLES_PER_STRATUM = 32_000_000
 SPATIAL_ORDER_MAX_STRATA = 400
-# Footprints at least this many pixels wide take kernel I (csrc/tsp_integrated.hip: second differences + two prefix sums of
-# the image) instead of the per-pixel kernels.  0 = off (the default: its result is exact to ~1e-6 of a footprint's PEAK
-# value, not of every pixel's own value -- tests/test_gpu_integrated.py); 256 takes a quarter off the frame time of a
-# 1e8-particle density render.  Must be 0 or >= 128.
-INTEGRATED_FOOTPRINT_PX = 0
 # Several GPUs behind one Visualizer (multigpu.py): how the caller's particle order is cut into shards.  "contiguous" =
 # index ranges [g N / G, (g + 1) N / G) (split_buffers.py:26-38); "interleaved" = blocks of MULTI_GPU_INTERLEAVE_BLOCK
 # consecutive particles dealt to the shards in turn; "auto" = interleaved when the loader brings its own cell layout (its

@@ -104,7 +104,7 @@ using namespace tsp;
 extern "C" {
 
 const char *tsp_last_error(void) { return g_err; }
-int tsp_version(void) { return 104; }     // 101: tsp_stats gained ms_mega, n_mega (16 bytes); 102: the per-kernel fragment counts (32 bytes); 103: n_chunk_culled (8 bytes); 104: matrix-core options removed
+int tsp_version(void) { return 104; }     // 101: tsp_stats gained ms_mega, n_mega (16 bytes); 102: the per-kernel fragment counts (32 bytes); 103: n_chunk_culled (8 bytes); 104: matrix-core / kernel-I options removed
 int tsp_stats_size(void) { return (int)sizeof(tsp_stats); }
 
 int tsp_device_count(void) {
@@ -171,8 +171,8 @@ void tsp_destroy(tsp_context *ctx) {
     tsp_comm_destroy(ctx);
     free_particles(ctx);
     void *ptrs[] = {ctx->image, ctx->image64, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->lut2d, ctx->scratch,
-                    ctx->ws.mid_geom, ctx->ws.mid_w, ctx->ws.huge_geom, ctx->ws.huge_w, ctx->ws.seg_count, ctx->ws.seg_offset,
-                    ctx->ws.seg_bbox, ctx->ws.band_count, ctx->ws.band_list, ctx->ws.block_bounds, ctx->ws.alive_list, ctx->ws.cull_info, ctx->ws.range_prefix, ctx->ws.count_diff, ctx->ws.count_band, ctx->ws.int_d2, ctx->ws.int_part, ctx->ws.int_wmax, ctx->int_tables, ctx->sort_keys, ctx->sort_keys_alt, ctx->sort_tmp};
+                    ctx->ws.mid_geom, ctx->ws.mid_w, ctx->ws.huge_geom, ctx->ws.huge_w, ctx->ws.hband_geom, ctx->ws.hband_w, ctx->ws.hband_count, ctx->ws.seg_count, ctx->ws.seg_offset,
+                    ctx->ws.seg_bbox, ctx->ws.band_count, ctx->ws.band_list, ctx->ws.block_bounds, ctx->ws.alive_list, ctx->ws.cull_info, ctx->ws.range_prefix, ctx->ws.count_diff, ctx->ws.count_band, ctx->sort_keys, ctx->sort_keys_alt, ctx->sort_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &e : ctx->ev)
@@ -210,17 +210,6 @@ int tsp_set_kernel_mips(tsp_context *ctx, const float *lut, int n0, int n_levels
                 if (memcmp(&lut[off + j * n + i], &lut[off + j * n + (n - 1 - i)], 4) || memcmp(&lut[off + j * n + i], &lut[off + (n - 1 - j) * n + i], 4)) { sym = false; break; }
     }
     ctx->lut_mirror_symmetric = sym;
-    {   // kernel I (option integrated_px): breakpoint strengths of the level-0 image and their prefix sums, in float64
-        std::vector<double> tables;
-        integrated_tables(lut, tables);
-        ctx->int_edge[0] = ctx->int_edge[1] = 0;
-        ctx->int_peak = 0.0f;
-        for (int i = 0; i < 64 * 64; ++i) ctx->int_peak = std::max(ctx->int_peak, fabsf(lut[i]));
-        for (int q = 0; q < 66; ++q)
-            if (tables[(size_t)q * INT_S0_STRIDE] != 0.0 || tables[(size_t)q * INT_S0_STRIDE + 65] != 0.0) ctx->int_edge[q >> 6] |= 1ull << (q & 63);
-        if (!ctx->int_tables) TSP_HIP(hipMalloc((void **)&ctx->int_tables, tables.size() * sizeof(double)));
-        TSP_HIP(hipMemcpy(ctx->int_tables, tables.data(), tables.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
     return TSP_OK;
 }
 
@@ -468,7 +457,6 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
     ctx->image_is_reduced = false;                             // `image` is this rank's partial image again
     TSP_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     TSP_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->ws.int_dirty = false;                                 // kernel I's pass (if any) completed: its D2 is all-zero again
     float ms = 0.f;
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->stats.ms_total = ms;
@@ -476,15 +464,15 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
     TSP_HIP(hipMemcpy(&hc, ctx->counters, sizeof(hc), hipMemcpyDeviceToHost));
     ctx->stats.n_small = (int64_t)hc.n_small;
     ctx->stats.n_mid = (int64_t)hc.n_mid;
-    ctx->stats.n_huge = (int64_t)(hc.n_huge + hc.n_mega);
-    ctx->stats.n_mega = (int64_t)hc.n_mega;
+    ctx->stats.n_huge = (int64_t)hc.n_huge;
+    ctx->stats.n_mega = 0;
     ctx->stats.n_culled = (int64_t)hc.n_culled + ctx->chunk_culled_particles;
     ctx->stats.n_chunk_culled = ctx->chunk_culled_particles;
     ctx->stats.n_fragments = (int64_t)hc.n_fragments;
     ctx->stats.n_fragments_stream = (int64_t)hc.n_frag_class[0];
     ctx->stats.n_fragments_mid = (int64_t)hc.n_frag_class[1];
     ctx->stats.n_fragments_huge = (int64_t)hc.n_frag_class[2];
-    ctx->stats.n_fragments_mega = (int64_t)hc.n_frag_class[3];
+    ctx->stats.n_fragments_mega = 0;
     if (gpu_ms_out) *gpu_ms_out = ms;
     return TSP_OK;
 }
@@ -715,11 +703,6 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         ctx->debug_extra_lds = (int)value;
         return TSP_OK;
     }
-    if (!strcmp(name, "mega_split")) {        // workgroups per tile of kernel I
-        TSP_REQUIRE(value >= 0 && value <= 4096, TSP_EINVAL, "%s out of range", name);
-        ctx->mega_split = (int)value;
-        return TSP_OK;
-    }
     if (!strcmp(name, "mid_split") || !strcmp(name, "huge_split") || !strcmp(name, "stream_blocks_per_cu")) {
         TSP_REQUIRE(value >= 0 && value <= 4096, TSP_EINVAL, "%s out of range", name);
         if (name[0] == 'm') ctx->mid_split = value > 0 ? (int)value : 1;
@@ -727,14 +710,9 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         else ctx->stream_blocks_per_cu = value > 0 ? (int)value : 1;
         return TSP_OK;
     }
-    if (!strcmp(name, "integrated_px")) {     // density footprints at least this wide go through kernel I (0 = off, else >= 128: below that the
-        // clamp-to-edge rim of the square is narrower than a pixel and the edge jumps are no longer pure steps)
-        TSP_REQUIRE(value == 0 || (value >= 128 && value <= 1000000), TSP_EINVAL, "integrated_px must be 0 or >= 128, got %lld", (long long)value);
-        ctx->integrated_px = (float)value;
-        if (value == 0) {                                      // switched off: give the second-difference images back (nch R^2 doubles)
-            TSP_HIP(hipSetDevice(ctx->device));
-            integrated_release(ctx);
-        }
+    if (!strcmp(name, "huge_band_mib")) {     // memory the band bins of the huge records may take, MiB (0 = never bin: kernel H2 scans one list)
+        TSP_REQUIRE(value >= 0 && value <= (1 << 20), TSP_EINVAL, "%s out of range", name);
+        ctx->huge_band_budget = value << 20;
         return TSP_OK;
     }
     if (!strcmp(name, "huge_variant")) {
@@ -744,7 +722,8 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         return TSP_OK;
     }
     if (!strcmp(name, "reorder_interleave")) {   // read by the next tsp_reorder_spatial
-        ctx->reorder_interleave = value != 0;
+        TSP_REQUIRE(value >= 0 && value <= 2, TSP_EINVAL, "%s out of range", name);
+        ctx->reorder_interleave = (int)value;      // 0: Morton order inside the blocks, 1: 64 x 8 transposition, 2: by descending h
         return TSP_OK;
     }
     if (!strcmp(name, "chunk_cull")) {        // 1 (default): kernel S skips the chunks whose bounds lie outside the view

@@ -4,9 +4,9 @@
 // (src/topsy/shaders/sph.wgsl:139-165, sampler src/topsy/sph.py:425-426) in the arithmetic of tsp_math.h; the records it
 // consumes (pixel-space centre, width, weights) are written by kernel S (tsp_pipeline.hip).
 //   kernel H2  splat_huge2_kernel  row-uniform gather: every footprint >= 64 px, every mode
-// (Rounds 1-4 also carried the per-pixel gather kernel H and the matrix-core kernels H3 / H4: none was selected by a default
-// rule any more -- f32 MFMA has no peak advantage over the VALU on gfx950 and H2 issues half the flop -- so round 5 removed
-// them; HISTORY.md keeps their measurements.)
+// (Rounds 1-4 also carried the per-pixel gather kernel H, the matrix-core kernels H3 / H4 and the option kernel I: none was
+// selected by a default rule -- f32 MFMA has no peak advantage over the VALU on gfx950 and H2 issues half the flop; kernel I is
+// exact only to ~1e-6 of a footprint's peak -- so round 5 removed them; HISTORY.md keeps their designs and measurements.)
 #include <algorithm>
 #include <type_traits>
 
@@ -112,14 +112,25 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     // workgroups of a tile in runs of HDEAL: consecutive records are spatial neighbours (consecutive chunks), so
     // every workgroup sees an even sample of the tile's footprints.
     // 32-bit record indices (the launcher refuses lists of 2^31 records or more)
-    const unsigned n_rec = (unsigned)a.n_records, n_runs = (n_rec + HDEAL - 1) / HDEAL, usplit = (unsigned)a.split;
+    // With band bins (huge_band_fill_kernel) the tile scans only the records whose squares reach its 64-row image band:
+    // ~1/3 of the list for the reference h-law at 1024^2, the same records in the same dealing
+    const float4 *geom = a.geom;
+    const float *wts = a.w;
+    unsigned n_rec = (unsigned)a.n_records;
+    if (a.hband_count) {
+        const int band = ty0 / HBAND_H;
+        geom += (size_t)band * a.hband_stride;
+        wts += (size_t)band * a.hband_stride * NW;
+        n_rec = (unsigned)a.hband_count[band];
+    }
+    const unsigned n_runs = (n_rec + HDEAL - 1) / HDEAL, usplit = (unsigned)a.split;
     auto fetch = [&](unsigned run0, float4 &g, float &gw1, float &gw2) {
         const unsigned ri = ((run0 + lane / HDEAL) * usplit + sp) * HDEAL + (lane & (HDEAL - 1));
         g = make_float4(0.f, 0.f, 0.f, 0.f); gw1 = gw2 = 0.0f;
         if (ri < n_rec) {
-            g = a.geom[ri];
-            gw1 = a.w[ri * NW];
-            if (NW == 2) gw2 = a.w[ri * NW + 1];
+            g = geom[ri];
+            gw1 = wts[ri * NW];
+            if (NW == 2) gw2 = wts[ri * NW + 1];
         }
     };
     float4 g_next; float gw1_next, gw2_next;
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
         {
             const float sdx = fmaxf(fmaxf(sx0 - g.x, g.x - sx1), 0.0f), sdy = fmaxf(fmaxf(sy0 - g.y, g.y - sy1), 0.0f);
             // g.z = 0 marks an empty slot; the kernel vanishes outside the disc inscribed in the footprint square
-            hit = g.z > 0.0f && g.z < a.p_hi && sdx < g_half && sdy < g_half && !(a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * g.z * g.z);
+            hit = g.z > 0.0f && sdx < g_half && sdy < g_half && !(a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * g.z * g.z);
         }
         unsigned long long hits = __ballot(hit);
         if (hits == 0ull) continue;
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 #undef TSP_H2_GROUP
 #undef TSP_H2_ROW
             if (CNT) n_frag += (unsigned long long)(ncov_x * __popcll((unsigned long long)covmask));
-#ifdef TSP_H2_DEBUG      // analysis build: (footprint, strip) pairs, covered rows and texel-row changes instead of the S / M / I fragment counts
+#ifdef TSP_H2_DEBUG      // analysis build: (footprint, strip) pairs, covered rows and texel-row changes instead of the S / M fragment counts
             if (CNT && lane == 0) {
                 atomicAdd(&a.cnt->n_frag_class[0], 1ull);
                 atomicAdd(&a.cnt->n_frag_class[1], (unsigned long long)__popcll((unsigned long long)covmask));
@@ -345,6 +356,96 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// band bins of the huge records
+// ---------------------------------------------------------------------------------------------
+// Every tile of kernel H2 used to scan the WHOLE huge list (at 1e9 particles: 128 tiles x 85 MB through eight non-coherent
+// L2s = 12.7 GB of fabric reads per launch, and 1/12 of the kernel's instructions spent on records that cannot reach the tile).
+// One pass copies every record into the bin of each 64-row image band its square reaches (a square of P pixels reaches
+// P / 64 + 1 or + 2 of them; one pixel of margin per side so that float rounding can only add a band, never drop one -- kernel
+// H2 repeats the exact test per strip).  Bins are fixed regions of n_huge records each, so no sizes need to be known first;
+// a workgroup reserves its slots per band with ONE global atomic (counts formed in LDS): the 12-ns same-address atomics that
+// made per-record binning cost 3.3 ms in round 2 are ~n_bands per 1024 records here.
+template <int NW>
+__global__ __launch_bounds__(256) void huge_band_fill_kernel(const float4 *__restrict__ geom, const float *__restrict__ w, long long n,
+                                                             int R, int n_bands, float4 *__restrict__ out_geom, float *__restrict__ out_w,
+                                                             long long stride, int *__restrict__ band_count) {
+    constexpr int PER = 4;                 // records per thread
+    extern __shared__ int s_band[];        // [n_bands] counts, then [n_bands] bases
+    int *s_cnt = s_band, *s_base = s_band + n_bands;
+    for (int b = threadIdx.x; b < n_bands; b += 256) s_cnt[b] = 0;
+    __syncthreads();
+    const long long first = ((long long)blockIdx.x * 256 + threadIdx.x) * PER;
+    float4 g[PER];
+    int b0[PER], b1[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        b0[k] = 1; b1[k] = 0;
+        if (first + k < n) {
+            g[k] = geom[first + k];
+            const float half = 0.5f * g[k].z, lo = g[k].y - half - 1.0f, hi = g[k].y + half + 1.0f;
+            // (non-finite or off-image squares: no band; kernel S emits only records that cover a pixel)
+            if (hi >= 0.0f && lo < (float)R && lo == lo && hi == hi) {
+                b0[k] = max(0, (int)__builtin_floorf(fmaxf(lo, 0.0f) * (1.0f / HBAND_H)));
+                b1[k] = min(n_bands - 1, (int)__builtin_floorf(fminf(hi, (float)R) * (1.0f / HBAND_H)));
+            }
+            for (int b = b0[k]; b <= b1[k]; ++b) atomicAdd(&s_cnt[b], 1);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < n_bands; b += 256) {
+        const int c = s_cnt[b];
+        s_base[b] = c ? atomicAdd(&band_count[b], c) : 0;
+        s_cnt[b] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (first + k >= n || b0[k] > b1[k]) continue;
+        float w0 = w[(first + k) * NW], w1 = (NW == 2) ? w[(first + k) * NW + 1] : 0.0f;
+        for (int b = b0[k]; b <= b1[k]; ++b) {
+            const long long slot = (long long)b * stride + s_base[b] + atomicAdd(&s_cnt[b], 1);
+            out_geom[slot] = g[k];
+            out_w[slot * NW] = w0;
+            if (NW == 2) out_w[slot * NW + 1] = w1;
+        }
+    }
+}
+
+// bins the huge list when that pays and fits the memory budget; sets ta.hband_* (or leaves them null)
+template <int NW>
+static int bin_huge_records(tsp_context *ctx, TileArgs &ta, const float4 *huge_geom, const float *huge_w, long long n_huge) {
+    ta.hband_count = nullptr; ta.hband_stride = 0;
+    Workspace &ws = ctx->ws;
+    const int n_bands = (ctx->R + HBAND_H - 1) / HBAND_H;
+    const size_t rec_bytes = sizeof(float4) + NW * sizeof(float);
+    // (one band: nothing to gain; a short list is scanned in microseconds; a huge image with a long list would not fit)
+    if (n_bands < 2 || n_huge < 4096 || (long long)n_bands * n_huge * (long long)rec_bytes > ctx->huge_band_budget) return TSP_OK;
+    if (ws.hband_stride < n_huge || ws.hband_bands < n_bands) {
+        if (ws.hband_geom) TSP_HIP(hipFree(ws.hband_geom));
+        if (ws.hband_w) TSP_HIP(hipFree(ws.hband_w));
+        if (ws.hband_count) TSP_HIP(hipFree(ws.hband_count));
+        ws.hband_geom = ws.hband_w = nullptr; ws.hband_count = nullptr;
+        ws.hband_stride = n_huge + n_huge / 8 + 1024;
+        ws.hband_bands = n_bands;
+        const size_t slots = (size_t)n_bands * (size_t)ws.hband_stride;
+        if ((long long)slots * (long long)(sizeof(float4) + 2 * sizeof(float)) > ctx->huge_band_budget + (ctx->huge_band_budget >> 2)) ws.hband_stride = n_huge;
+        const size_t slots2 = (size_t)n_bands * (size_t)ws.hband_stride;
+        TSP_HIP(hipMalloc(&ws.hband_geom, slots2 * sizeof(float4)));
+        TSP_HIP(hipMalloc(&ws.hband_w, slots2 * 2 * sizeof(float)));
+        TSP_HIP(hipMalloc((void **)&ws.hband_count, 256 * sizeof(int)));
+    }
+    hipStream_t st = ctx->stream;
+    TSP_HIP(hipMemsetAsync(ws.hband_count, 0, 256 * sizeof(int), st));
+    const unsigned grid = (unsigned)((n_huge + 1023) / 1024);
+    hipLaunchKernelGGL((huge_band_fill_kernel<NW>), dim3(grid), dim3(256), 2 * n_bands * sizeof(int), st, huge_geom, huge_w, n_huge, ctx->R, n_bands,
+                       (float4 *)ws.hband_geom, (float *)ws.hband_w, (long long)ws.hband_stride, ws.hband_count);
+    TSP_HIP(hipGetLastError());
+    ta.geom = (const float4 *)ws.hband_geom; ta.w = (const float *)ws.hband_w;
+    ta.hband_count = ws.hband_count; ta.hband_stride = ws.hband_stride;
+    return TSP_OK;
+}
+
 template <int MODE, int NACC, int W, int HR, int OCC>
 static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
     TSP_REQUIRE(ta.n_records < (1ll << 31), TSP_EINVAL, "%lld deferred footprints in one render block (the tile-gather kernels index them with 32 bits)", ta.n_records);
@@ -358,8 +459,14 @@ static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
     // cost 2.5 ms of 21; measured 64 -> 128: 21.9 -> 19.5 ms, 256: 19.2 ms, 512: 22.5 ms
     if (split <= 0) {
         split = std::max(1, (ctx->cu_count * 128 + htiles - 1) / htiles);
-        // a small render block: fewer, longer workgroups (each loads the kernel image) in proportion below 2^16 records
-        if (n_huge < (1ll << 16)) split = std::max(32, (int)((long long)split * n_huge >> 16));
+        // Fewer, longer workgroups for shorter record lists: every workgroup loads the kernel image and each of its waves walks its
+        // share of the list at memory latency (64 records per step), so below ~2e6 records the scan outweighs the balance that many
+        // short workgroups buy.  Round 5, 1024^2, workgroups per 128x64 tile (64x32 strips): 4.2e6 records 192 / 256 / 384 -> 33.2 /
+        // 33.05 / 32.8 ms; 1.2e6: 128 / 192 / 256 / 384 -> 10.29 / 10.05 / 10.37 / 11.1; 5.3e5 (one of 8 shards of the 1e9 snapshot):
+        // 64 / 96 / 128 / 192 / 256 -> 5.32 / 4.90 / 4.76 / 4.85 / 5.38; 3.4e5: 64 / 128 / 256 -> 4.24 / 3.42 / 4.45
+        if (n_huge < (1ll << 16)) split = std::max(32, (int)((long long)split * n_huge >> 16));      // a small render block: in proportion
+        else if (HR == 32 && NACC == 1) split = n_huge >= 2000000 ? split : (n_huge >= 1000000 ? (split * 3) / 4 : split / 2);
+        else if (HR == 16 && NACC == 1) split = std::max(1, split / 2);      // (64x16 strips serve < 2.5e5 records: 32 / 64 / 128 per 128x32 tile -> 2.64 / 2.18 / 2.38 ms at 1.5e5)
     }
     split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
     ta.split = split;
@@ -375,12 +482,13 @@ static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
 // ---------------------------------------------------------------------------------------------
 template <int MODE>
 static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel, const float4 *huge_geom, const float *huge_w,
-                              long long n_huge, const float4 *mega_geom, const float *mega_w, long long n_mega) {
+                              long long n_huge) {
     hipStream_t st = ctx->stream;
     int rc = TSP_OK;
-    ta.p_lo = 0.0f; ta.p_hi = __builtin_inff();
     if (n_huge > 0) {
         ta.geom = huge_geom; ta.w = huge_w; ta.n_records = n_huge;
+        TSP_REQUIRE(n_huge < (1ll << 31), TSP_EINVAL, "%lld deferred footprints in one render block (the tile-gather kernel indexes them with 32 bits)", n_huge);
+        if ((rc = bin_huge_records<(MODE == TSP_MODE_RGB) ? 2 : 1>(ctx, ta, huge_geom, huge_w, n_huge))) return rc;
         if (MODE == TSP_MODE_RGB) {
             // three accumulator sets: 96 VGPRs at 5 waves/SIMD (11.5 against 12.5 ms at 4 for the 64-128 px band of config 4)
             if (ctx->huge_variant == 4) rc = launch_huge2<MODE, 3, 1, 16, 4>(ctx, ta, n_huge);
@@ -396,28 +504,23 @@ static int launch_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel
         else if (ctx->huge_variant == 6) rc = launch_huge2<MODE, 1, 1, 32, 7>(ctx, ta, n_huge);
         // Density: 64x32 strips with the row factors fetched group by group -- half as many (footprint, strip) pairs to set up --
         // at 8 waves/SIMD (64 VGPRs): this kernel is latency-bound per wave, occupancy is what pays.  1.25e8 particles, records
-        // 64-768 px: 10.20 / 9.86 / 9.59 ms at 6 / 7 / 8 waves (1e9: 28.7 / 26.9 / 26.9); 64x16 strips at 8: 10.7.  With fewer
-        // records the shorter strips' finer work units win (3.4e5 records: 3.05 against 3.49 ms)
-        else if (ctx->huge_variant == 7 || (ctx->huge_variant == 1 && n_huge >= 700000)) rc = launch_huge2<MODE, 1, 1, 32, 8>(ctx, ta, n_huge);
+        // 64-768 px: 10.20 / 9.86 / 9.59 ms at 6 / 7 / 8 waves (1e9: 28.7 / 26.9 / 26.9); 64x16 strips at 8: 10.7.  Round 5 re-measured
+        // the cross-over with the workgroup count tuned per strip shape (launch_huge2): 64x32 strips win from ~2.5e5 records
+        // (5.3e5: 4.76 against 5.47 ms; 3.4e5: 3.42 against 3.81; 1.5e5: 2.22 against 2.18)
+        else if (ctx->huge_variant == 7 || (ctx->huge_variant == 1 && n_huge >= 250000)) rc = launch_huge2<MODE, 1, 1, 32, 8>(ctx, ta, n_huge);
         else rc = launch_huge2<MODE, 1, 1, 16, 8>(ctx, ta, n_huge);
         if (rc) return rc;
     }
     TSP_HIP(hipEventRecord(ctx->ev[10], st));
-    if (n_mega > 0 && integrated_active(ctx)) {     // option integrated_px: kernel I takes the records at least that wide (the tail end of the huge list)
-        ta.geom = mega_geom; ta.w = mega_w; ta.n_records = n_mega;
-        rc = launch_integrated(ctx, ta, mega_geom, mega_w, MODE == TSP_MODE_RGB ? 2 : (second_channel ? 1 : 0), n_mega, ctx->integrated_px);
-        if (rc) return rc;
-    }
-    TSP_HIP(hipEventRecord(ctx->ev[11], st));
     return TSP_OK;
 }
 
 int launch_gather_kernels(tsp_context *ctx, TileArgs ta, int mode, bool second_channel, const float4 *huge_geom, const float *huge_w,
-                          long long n_huge, const float4 *mega_geom, const float *mega_w, long long n_mega) {
+                          long long n_huge) {
     switch (mode) {
-        case TSP_MODE_WEIGHTED: return launch_gather_mode<TSP_MODE_WEIGHTED>(ctx, ta, second_channel, huge_geom, huge_w, n_huge, mega_geom, mega_w, n_mega);
-        case TSP_MODE_DEPTH: return launch_gather_mode<TSP_MODE_DEPTH>(ctx, ta, true, huge_geom, huge_w, n_huge, mega_geom, mega_w, n_mega);
-        case TSP_MODE_RGB: return launch_gather_mode<TSP_MODE_RGB>(ctx, ta, true, huge_geom, huge_w, n_huge, mega_geom, mega_w, n_mega);
+        case TSP_MODE_WEIGHTED: return launch_gather_mode<TSP_MODE_WEIGHTED>(ctx, ta, second_channel, huge_geom, huge_w, n_huge);
+        case TSP_MODE_DEPTH: return launch_gather_mode<TSP_MODE_DEPTH>(ctx, ta, true, huge_geom, huge_w, n_huge);
+        case TSP_MODE_RGB: return launch_gather_mode<TSP_MODE_RGB>(ctx, ta, true, huge_geom, huge_w, n_huge);
     }
     set_error("bad mode %d", mode);
     return TSP_EINVAL;

@@ -60,8 +60,8 @@ struct Record4 {   // rgb variant (24 B)
 };
 
 struct Counters {      // device-side, zeroed per render call
-    unsigned long long n_small, n_mid, n_huge, n_culled, n_fragments, huge_count, n_mega, pad1;
-    unsigned long long n_frag_class[4];   // n_fragments by the kernel that drew them: S, M, H2, I
+    unsigned long long n_small, n_mid, n_huge, n_culled, n_fragments, huge_count, pad0, pad1;
+    unsigned long long n_frag_class[4];   // n_fragments by the kernel that drew them: S, M, H2, (unused)
 };
 
 struct Workspace {     // per-context scratch of the three-class pipeline (grown on demand)
@@ -69,6 +69,9 @@ struct Workspace {     // per-context scratch of the three-class pipeline (grown
     int64_t mid_capacity = 0;
     void *huge_geom = nullptr, *huge_w = nullptr;   // deferred huge footprints
     int64_t huge_capacity = 0;
+    void *hband_geom = nullptr, *hband_w = nullptr; // the huge records once more, binned by 64-row image band (n_bands regions of hband_stride records)
+    int *hband_count = nullptr;                     // records per band
+    int64_t hband_stride = 0; int hband_bands = 0;
     int *seg_count = nullptr;           // per chunk: number of mid records
     long long *seg_offset = nullptr;    // per chunk: first record of its contiguous run
     float4 *seg_bbox = nullptr;         // per chunk: pixel bbox of its mid footprints (x0, y0, x1, y1)
@@ -85,11 +88,6 @@ struct Workspace {     // per-context scratch of the three-class pipeline (grown
     int64_t range_capacity = 0;
     int *count_diff = nullptr;          // rgb: (R+1)^2 corner-difference image of the huge footprints' pixel rectangles
     int *count_band = nullptr;          // rgb: per (64-row band, column) sums of its row-scanned form
-    double *int_d2 = nullptr;           // kernel I: [int_channels] R x R second-difference images (zero between render blocks)
-    int int_channels = 0;
-    bool int_dirty = false;             // kernel I: a pass was issued and has not been seen to complete (D2 may hold stale second differences)
-    unsigned int *int_wmax = nullptr;   // kernel I: per channel, the largest |weight| of the pass (float bits)
-    void *int_part = nullptr;           // kernel I: per (32-row segment, column) partial sums of the column pass
 };
 
 }  // namespace tsp
@@ -132,13 +130,10 @@ struct tsp_context {
     bool count_fragments = false;
     // pipeline tuning (tsp_set_option)
     float p_small = 16.0f;             // footprints narrower than this many pixels are splatted by kernel S (mips 3 and 2; <= 16: its texel columns are packed 16 x 4 bits)
-    float integrated_px = 0.0f;       // option: density footprints at least this wide (>= 128) go through kernel I (second differences + prefix sums, tsp_integrated.hip); 0 = off
-    float int_peak = 0.0f;            // kernel I: largest level-0 texel
-    unsigned long long int_edge[2] = {0, 0};   // kernel I: rows of S0 with a non-zero edge jump (bit q of 66)
-    double *int_tables = nullptr;     // kernel I: breakpoint strengths of the level-0 kernel image and their prefix sums (integrated_tables)
+    int64_t huge_band_budget = 6ll << 30;   // bytes the band bins of the huge records may take (n_bands x n_huge records); above it kernel H2 scans one list
     int huge_variant = 1;             // kernel H2's strip shape / occupancy: 1 = auto (density: 64x32 strips at 8 waves/SIMD from 7e5 records, 64x16 below; two channels 64x16 at 7; rgb at 5), 2 / 4-7 = A/B builds
-    int mid_split = 128, huge_split = 0, mega_split = 0;  // workgroups per image tile of kernels M / H2 / I (0 = auto)
-    bool reorder_interleave = true;  // tsp_reorder_spatial transposes every 512-particle block 64 x 8 (lane decorrelation for kernel S, tsp_data.hip)
+    int mid_split = 128, huge_split = 0;  // workgroups per image tile of kernels M / H2 (0 = auto)
+    int reorder_interleave = 1;     // tsp_reorder_spatial transposes every 512-particle block 64 x 8 (lane decorrelation for kernel S, tsp_data.hip)
     int stream_blocks_per_cu = 100;  // kernel S grid bound: ~10 chunks per workgroup at 1e8 particles balances dense and sparse chunks
     bool chunk_cull = true;           // chunks (512 consecutive particles) whose bounds lie outside the view are skipped by kernel S
                                       // unread: pays with a load-time spatial order (tsp_reorder_spatial); identical results
@@ -188,11 +183,4 @@ int launch_image_convert(tsp_context *ctx, bool to_float);
 int tile_periodic(tsp_context *ctx, int n, const float *h_offsets, const float *h_weights);
 int content_sort(tsp_context *ctx, int kind, float scale, int64_t *n_finite, int64_t *n_nonpositive);   // image64 -> image (true) or image -> image64 (false)
 int ensure_array(float **p, int64_t n);
-constexpr int INT_S0_STRIDE = 68;   // doubles per row of kernel I's breakpoint tables (66 used)
-constexpr int INT_O_PA = 66 * INT_S0_STRIDE, INT_O_PB = INT_O_PA + 66 * INT_S0_STRIDE, INT_O_PAY = INT_O_PB + 66 * INT_S0_STRIDE;
-constexpr int INT_O_PBY = INT_O_PAY + 65 * INT_S0_STRIDE, INT_O_M = INT_O_PBY + 65 * INT_S0_STRIDE;
-constexpr int INT_TABLE_DOUBLES = INT_O_M + 65 * 65 * 4;
-bool integrated_supported(const tsp_context *ctx);
-void integrated_release(tsp_context *ctx);
-void integrated_tables(const float *mip0, std::vector<double> &out);
 }  // namespace tsp

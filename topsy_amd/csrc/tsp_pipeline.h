@@ -35,9 +35,10 @@ constexpr int MSTR = 72;             // LDS row stride (doubles) of the mid tile
 // edge of kernel S's LDS window by the number of channels it holds (1: density, 2: weighted / depth, 4: rgb)
 template <int WC> struct WinSize { static constexpr int value = (WC == 1) ? TSP_WIN1 : (WC == 2 ? TSP_WIN2 : TSP_WIN4); };
 
+constexpr int HBAND_H = 64;          // image rows per band of the huge-record bins (kernel H2's tallest tile)
 constexpr int NBANDS = 32;           // image bands of the chunk lists kernel S bins for kernel M (each a whole number of 32-row tile rows)
 
-enum { CLS_NONE = 0, CLS_SMALL = 1, CLS_MID = 2, CLS_HUGE = 3, CLS_MEGA = 4 };
+enum { CLS_NONE = 0, CLS_SMALL = 1, CLS_MID = 2, CLS_HUGE = 3 };
 
 // the render target is accumulated in float64 (global_atomic_add_f64) and rounded to float32 once per
 // tsp_render call, so cross-workgroup summation adds no float32 noise however many flushes hit a pixel
@@ -72,19 +73,14 @@ struct TileArgs {
     int tiles_x, split;
     int count_frag;
     float disc_k2;     // (0.5235)^2 when the LUT is zero outside the inscribed disc (exact corner culling), else 0
-    float p_lo, p_hi;  // kernel H2 takes the records with p_lo <= P < p_hi
+    // kernel H2: the huge records binned by image band (huge_band_fill_kernel): band b (rows [b, b + 1) * HBAND_H) holds
+    // hband_count[b] records at geom + b * hband_stride (w likewise); nullptr = one list for every tile (geom, n_records)
+    const int *hband_count; long long hband_stride;
 };
 
-// Kernel H2 (tsp_gather.hip) for the footprints >= 64 px of one render block: `huge_*` = the records below the option
-// integrated_px (all of them by default), `mega_*` = the records at least that wide, which kernel I draws.  Records ctx->ev[10]
-// between the two launches and ctx->ev[11] after them (per-kernel times).
-int launch_gather_kernels(tsp_context *ctx, TileArgs ta, int mode, bool second_channel, const float4 *huge_geom,
-                          const float *huge_w, long long n_huge, const float4 *mega_geom, const float *mega_w, long long n_mega);
-
-// Kernel I (tsp_integrated.hip, option `integrated_px`): the mega records through second differences, one pass per channel.
-int launch_integrated(tsp_context *ctx, const TileArgs &ta, const float4 *geom, const float *wq, int wmode, long long n_records, float p_lo);
-inline bool integrated_active(const tsp_context *ctx) {
-    return ctx->integrated_px >= 128.0f && integrated_supported(ctx);
-}
+// Kernel H2 (tsp_gather.hip) for the footprints >= 64 px of one render block (the records kernel S appended to the huge list).
+// Records ctx->ev[10] after the launch (per-kernel time: ev[9] .. ev[10]).
+int launch_gather_kernels(tsp_context *ctx, TileArgs ta, int mode, bool second_channel, const float4 *huge_geom, const float *huge_w,
+                          long long n_huge);
 
 }  // namespace tsp

@@ -12,7 +12,7 @@
 //             chunks are rasterised at once (ds_add_f64), flushed with one global atomic per touched
 //             pixel.  All other footprints are not rasterised here: their projected records
 //             (pcx, pcy, P, weights) are appended to the MID list (per-chunk contiguous segments with
-//             a pixel bounding box) or the HUGE list.
+//             a pixel bounding box) or the HUGE list (P >= 64 px).
 //   kernel M  splat_mid_kernel     one workgroup per (64x32 image tile, split): walks the segments
 //             whose bbox meets the tile; every lane prepares one record (tile-clipped pixel ranges,
 //             mip level), then each wave rasterises its records one at a time, parameters broadcast
@@ -104,7 +104,6 @@ struct StreamArgs {
     int *band_count; int *band_list; long long band_cap; int band_h;     // per image band: the chunks that have mid footprints there
     Counters *cnt;
     float p_small;
-    float p_mega;              // footprints at least this wide are appended from the END of the huge list (kernel I's share, option integrated_px; else +inf)
     int count_frag;
     int emit_small;            // 0: records only (replay after a record-list overflow)
     const int *alive;          // chunk culling: the chunks that may reach the view, nullptr = every chunk
@@ -370,13 +369,13 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         unsigned m_lo = 0xffffffffu, m_hi = 0u;      // the same for the mid footprints
         int my_counts = 0;                           // mid records | huge records << 16 of this lane
         Camera cam;                                  // (16 scalar registers, live in this phase only)
-        float p_small, p_mega;
+        float p_small;
         {
             CArgs *ap = KA();
 #pragma unroll
             for (int i = 0; i < 12; ++i) cam.m[i] = ap->cam.m[i];
             cam.sf = ap->cam.sf; cam.Rf = ap->cam.Rf; cam.halfR = ap->cam.halfR; cam.R = R;
-            p_small = ap->p_small; p_mega = ap->p_mega;
+            p_small = ap->p_small;
         }
         // Branch-free: every lane runs the whole classification on whatever its registers hold (lanes past the end of the chunk
         // re-read the chunk's last particle) and the outcome is masked at the end -- nothing below reads pcx .. w2, xr, yr of a
@@ -407,8 +406,8 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                 w2[k] = 0.0f;
             }
             pcx[k] = pr.pcx; pcy[k] = pr.pcy; PP[k] = pr.P;      // (1 / P is formed in phase 4, by the waves that rasterise)
-            const int c_of_p = (pr.P < p_small) ? CLS_SMALL : ((pr.P < P_BILINEAR) ? CLS_MID : ((pr.P < p_mega) ? CLS_HUGE : CLS_MEGA));
-            cls[k] = vis ? c_of_p : CLS_NONE;          // CLS_MEGA is rare (~1e-3 of the particles): one atomic each, below
+            const int c_of_p = (pr.P < p_small) ? CLS_SMALL : ((pr.P < P_BILINEAR) ? CLS_MID : CLS_HUGE);
+            cls[k] = vis ? c_of_p : CLS_NONE;
             const bool is_small = cls[k] == CLS_SMALL, is_mid = cls[k] == CLS_MID;
             s_lo = is_small ? pk_min_u16(s_lo, lo) : s_lo; s_hi = is_small ? pk_max_u16(s_hi, hi) : s_hi;
             m_lo = is_mid ? pk_min_u16(m_lo, lo) : m_lo; m_hi = is_mid ? pk_max_u16(m_hi, hi) : m_hi;
@@ -655,7 +654,6 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
             float4 *const mid_geom = ap->mid_geom, *const huge_geom = ap->huge_geom;
             float *const mid_w = ap->mid_w, *const huge_w = ap->huge_w;
             const long long mid_capacity = ap->mid_capacity, huge_capacity = ap->huge_capacity;
-            Counters *cntp = ap->cnt;
             long long mpos = mid_base + mid_before + (mid_incl - my_mid);
             long long hpos = huge_base + huge_before + (huge_incl - my_huge);
 #pragma unroll
@@ -674,16 +672,6 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                         if (NW == 2) huge_w[hpos * NW + 1] = w2[k];
                     }
                     ++hpos;
-                } else if (cls[k] == CLS_MEGA) {
-                    // the mega records grow downwards from the end of the huge list: one allocation, two cursors
-                    // (an overlap with the records growing from the front means overflow: the host sees
-                    // n_huge + n_mega > capacity, enlarges the list and replays)
-                    const long long mp = huge_capacity - 1 - (long long)atomicAdd(&cntp->n_mega, 1ull);
-                    if (mp >= 0) {
-                        huge_geom[mp] = make_float4(pcx[k], pcy[k], PP[k], w0[k]);
-                        huge_w[mp * NW] = w1[k];
-                        if (NW == 2) huge_w[mp * NW + 1] = w2[k];
-                    }
                 }
             }
         }
@@ -962,8 +950,7 @@ __global__ __launch_bounds__(256) void count_apply_kernel(const int *__restrict_
     }
 }
 
-static int add_rect_counts(tsp_context *ctx, const float4 *mid_geom, long long n_mid, const float4 *huge_geom, long long n_huge,
-                           const float4 *mega_geom, long long n_mega) {
+static int add_rect_counts(tsp_context *ctx, const float4 *mid_geom, long long n_mid, const float4 *huge_geom, long long n_huge) {
     Workspace &ws = ctx->ws;
     const int R = ctx->R, S = R + 1, nb = (R + CBAND - 1) / CBAND;
     if (!ws.count_diff) {
@@ -974,7 +961,6 @@ static int add_rect_counts(tsp_context *ctx, const float4 *mid_geom, long long n
     TSP_HIP(hipMemsetAsync(ws.count_diff, 0, (size_t)S * S * sizeof(int), st));
     if (n_mid > 0) hipLaunchKernelGGL(rect_count_corners_kernel, dim3((unsigned)((n_mid + 255) / 256)), dim3(256), 0, st, mid_geom, n_mid, R, ws.count_diff);
     if (n_huge > 0) hipLaunchKernelGGL(rect_count_corners_kernel, dim3((unsigned)((n_huge + 255) / 256)), dim3(256), 0, st, huge_geom, n_huge, R, ws.count_diff);
-    if (n_mega > 0) hipLaunchKernelGGL(rect_count_corners_kernel, dim3((unsigned)((n_mega + 255) / 256)), dim3(256), 0, st, mega_geom, n_mega, R, ws.count_diff);
     hipLaunchKernelGGL(count_row_scan_kernel, dim3(R), dim3(256), 0, st, ws.count_diff, R);
     hipLaunchKernelGGL(count_band_sum_kernel, dim3((R + 255) / 256, nb), dim3(256), 0, st, ws.count_diff, R, ws.count_band);
     hipLaunchKernelGGL(count_apply_kernel, dim3((R + 255) / 256, nb), dim3(256), 0, st, ws.count_diff, ws.count_band, R, ctx->image64);
@@ -1140,8 +1126,6 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         sa.band_count = ws.band_count; sa.band_list = ws.band_list; sa.band_cap = ws.band_capacity; sa.band_h = band_h;
         TSP_HIP(hipMemsetAsync(ws.band_count, 0, NBANDS * sizeof(int), st));
         sa.cnt = ctx->counters; sa.p_small = ctx->p_small;
-        // option integrated_px: the records at least that wide grow from the END of the huge list and go to kernel I
-        sa.p_mega = integrated_active(ctx) ? ctx->integrated_px : __builtin_inff();
         sa.count_frag = ctx->count_fragments ? 1 : 0;
         sa.emit_small = (attempt == 0 && !ctx->debug_no_raster) ? 1 : 0;
         TSP_HIP(hipEventRecord(ctx->ev[2], st));
@@ -1154,7 +1138,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         if (cull && attempt == 0) TSP_HIP(hipMemcpyAsync(cull_info_h, ws.cull_info, sizeof(cull_info_h), hipMemcpyDeviceToHost, st));
         TSP_HIP(hipStreamSynchronize(st));
         ctx->chunk_culled_particles = (int64_t)cull_info_h[1];
-        const bool mid_over = (int64_t)hc.n_mid > ws.mid_capacity, huge_over = (int64_t)(hc.n_huge + hc.n_mega) > ws.huge_capacity;
+        const bool mid_over = (int64_t)hc.n_mid > ws.mid_capacity, huge_over = (int64_t)hc.n_huge > ws.huge_capacity;
         if (!mid_over && !huge_over) break;
         TSP_REQUIRE(attempt == 0, TSP_ENOMEM, "record lists overflowed twice");
         // enlarge and replay kernel S in records-only mode (its small footprints are already in the image)
@@ -1164,7 +1148,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
             TSP_HIP(hipMalloc(&ws.mid_w, (size_t)ws.mid_capacity * 2 * sizeof(float)));
         }
         if (huge_over) {
-            if ((rc = grow(&ws.huge_geom, &ws.huge_capacity, (int64_t)(hc.n_huge + hc.n_mega) + (int64_t)(hc.n_huge + hc.n_mega) / 8 + 1024, sizeof(float4)))) return rc;
+            if ((rc = grow(&ws.huge_geom, &ws.huge_capacity, (int64_t)hc.n_huge + (int64_t)hc.n_huge / 8 + 1024, sizeof(float4)))) return rc;
             if (ws.huge_w) TSP_HIP(hipFree(ws.huge_w));
             TSP_HIP(hipMalloc(&ws.huge_w, (size_t)ws.huge_capacity * 2 * sizeof(float)));
         }
@@ -1210,14 +1194,10 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     }
     TSP_HIP(hipEventRecord(ctx->ev[5], st_mid));
     TSP_HIP(hipEventRecord(ctx->ev[9], st));
-    const long long n_mega = (long long)hc.n_mega;
-    const float4 *mega_geom = (const float4 *)ws.huge_geom + (ws.huge_capacity - n_mega);
-    const float *mega_w = (const float *)ws.huge_w + (ws.huge_capacity - n_mega) * ((MODE == TSP_MODE_RGB) ? 2 : 1);
-    if ((rc = launch_gather_kernels(ctx, ta, MODE, second_channel, (const float4 *)ws.huge_geom, (const float *)ws.huge_w,
-                                    (long long)hc.n_huge, mega_geom, mega_w, n_mega))) return rc;
-    if (MODE == TSP_MODE_RGB && (hc.n_mid > 0 || hc.n_huge > 0 || n_mega > 0)) {
+    if ((rc = launch_gather_kernels(ctx, ta, MODE, second_channel, (const float4 *)ws.huge_geom, (const float *)ws.huge_w, (long long)hc.n_huge))) return rc;
+    if (MODE == TSP_MODE_RGB && (hc.n_mid > 0 || hc.n_huge > 0)) {
         if (ctx->overlap_mid_huge) TSP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));
-        if ((rc = add_rect_counts(ctx, (const float4 *)ws.mid_geom, (long long)hc.n_mid, (const float4 *)ws.huge_geom, (long long)hc.n_huge, mega_geom, n_mega))) return rc;
+        if ((rc = add_rect_counts(ctx, (const float4 *)ws.mid_geom, (long long)hc.n_mid, (const float4 *)ws.huge_geom, (long long)hc.n_huge))) return rc;
     }
     TSP_HIP(hipEventRecord(ctx->ev[6], st));
     if (ctx->overlap_mid_huge) TSP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));     // join: later work on `st` sees both
@@ -1226,7 +1206,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[cull ? 7 : 2], ctx->ev[3])); ctx->stats.ms_stream = ms;
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->stats.ms_mid = ms;
     TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[9], ctx->ev[10])); ctx->stats.ms_huge = ms;
-    TSP_HIP(hipEventElapsedTime(&ms, ctx->ev[10], ctx->ev[11])); ctx->stats.ms_mega = ms;
+    ctx->stats.ms_mega = 0.0;
     return TSP_OK;
 }
 

@@ -41,8 +41,6 @@ class ParticleBuffers:
         else:
             self.context = _native.Context(resolution, 4, device_id if not device_ids else device_ids[0])
         self.context.set_kernel_mips(kernel_lut.kernel_mips())
-        if config.INTEGRATED_FOOTPRINT_PX:
-            self.context.set_option("integrated_px", int(config.INTEGRATED_FOOTPRINT_PX))
         self._upload_geometry()
 
     def _upload_geometry(self):
