@@ -377,38 +377,52 @@ def test_record_list_overflow_replay(native, mips, label, h_values):
         c2.close()
 
 
-def test_reorder_interleave_keeps_cells_and_images(native, mips):
-    """tsp_reorder_spatial transposes every 512-particle block of the Morton order 64 x 8 (lane decorrelation for kernel S,
-    option reorder_interleave, on by default).  The permutation stays a bijection, every (stratum, cell) run keeps exactly its
+def test_in_block_arrangements_keep_cells_and_images(native, mips):
+    """tsp_reorder_spatial rearranges every 512-particle block of the Morton order (option reorder_interleave: 2 = by
+    descending smoothing length, the default: the 64 particles of a kernel-S wave step then have nearly one footprint width;
+    1 = transposed 64 x 8; 0 = Morton order).  The permutation stays a bijection, every (stratum, cell) run keeps exactly its
     own particles (view culling by cell runs), and the render -- image and exact fragment count -- does not depend on it."""
     n, R = 300_000, 512
     M, sf = camera(200.0)
     out = {}
-    for inter in (1, 0):
+    for inter in (2, 1, 0):
         ctx = native.Context(R, 2)
         ctx.set_kernel_mips(mips)
         ctx.set_option("reorder_interleave", inter)
         ctx.generate_synthetic(n, 0, n, 1337, 0.0)
         perm = ctx.reorder_spatial(8, 1337, want_permutation=True)
         assert np.array_equal(np.sort(perm), np.arange(n))
+        h = ctx.download_particles(("h",))["h"]
         ctx.set_option("count_fragments", 1)
         ctx.render(M, sf)
-        out[inter] = (perm, ctx.cell_layout()["offsets"], ctx.strata_offsets(), ctx.read_image().astype(np.float64), ctx.stats()["n_fragments"])
+        out[inter] = (perm, ctx.cell_layout()["offsets"], ctx.strata_offsets(), ctx.read_image().astype(np.float64), ctx.stats()["n_fragments"], h)
         ctx.close()
-    (p1, c1, s1, img1, f1), (p0, c0, s0, img0, f0) = out[1], out[0]
-    assert np.array_equal(c1, c0) and np.array_equal(s1, s0)
-    assert not np.array_equal(p1, p0), "the interleave changed nothing"
-    for a, b in zip(c1[:-1][::37], c1[1:][::37]):          # a sample of the cell runs: the same particles, in another order
-        assert np.array_equal(np.sort(p1[a:b]), np.sort(p0[a:b]))
-    # inside one aligned block that lies in one cell: slot (r mod 8) * 64 + r / 8 holds Morton rank r
-    sizes = np.diff(c1)
+    p0, c0, s0, img0, f0, h0 = out[0]
+    sizes = np.diff(c0)
     big = int(np.argmax(sizes))
-    b0 = -(-int(c1[big]) // 512) * 512
-    assert b0 + 512 <= c1[big + 1]
+    b0 = -(-int(c0[big]) // 512) * 512          # an aligned block that lies inside the largest cell run
+    assert b0 + 512 <= c0[big + 1]
     r = np.arange(512)
-    assert np.array_equal(p1[b0 + (r % 8) * 64 + r // 8], p0[b0 + r])
-    assert f1 == f0
-    assert rel_close(img1[..., 0], img0[..., 0], 1e-5)
+    for inter in (1, 2):
+        p, c, s, img, f, h = out[inter]
+        assert np.array_equal(c, c0) and np.array_equal(s, s0)
+        assert not np.array_equal(p, p0), "the arrangement changed nothing"
+        for a, b in zip(c[:-1][::37], c[1:][::37]):          # a sample of the cell runs: the same particles, in another order
+            assert np.array_equal(np.sort(p[a:b]), np.sort(p0[a:b]))
+        assert np.array_equal(np.sort(p[b0:b0 + 512]), np.sort(p0[b0:b0 + 512]))
+        assert f == f0
+        assert rel_close(img[..., 0], img0[..., 0], 1e-5)
+    # transposition: slot (r mod 8) * 64 + r / 8 holds Morton rank r
+    assert np.array_equal(out[1][0][b0 + (r % 8) * 64 + r // 8], p0[b0 + r])
+    # by smoothing length: non-increasing inside the block, i.e. every wave step (64 slots) holds neighbours in h
+    hb = out[2][5][b0:b0 + 512]
+    assert (np.diff(hb) <= 0).all() and hb[0] > hb[-1]
+    # ... and inside every (block x cell run) segment elsewhere
+    c = out[2][1]
+    for a, b in zip(c[:-1][::53], c[1:][::53]):
+        for lo in range(int(a) - int(a) % 512, int(b), 512):
+            seg = out[2][5][max(lo, int(a)):min(lo + 512, int(b))]
+            assert (np.diff(seg) <= 0).all()
 
 
 def test_vertex_weights_follow_every_upload(native, mips):

@@ -6,6 +6,7 @@ import numpy.testing as npt
 import pytest
 
 import topsy_amd
+from topsy_amd import config
 from topsy_amd.drawreason import DrawReason
 
 pytestmark = pytest.mark.gpu
@@ -144,8 +145,8 @@ def test_progressive_frames_fold_mass_scale():
     # the library reordered the particles into strata: the block was rounded to whole strata (unbiased sample)
     bounds = v.particle_buffers.block_boundaries
     drawn = rp._start_index
-    assert len(bounds) == 33 and bounds[0] == 0 and bounds[-1] == 200000 and drawn in set(bounds.tolist())
-    assert abs(drawn - 50000) < 200000 // 32
+    assert len(bounds) == config.SPATIAL_ORDER_STRATA + 1 and bounds[0] == 0 and bounds[-1] == 200000 and drawn in set(bounds.tolist())
+    assert abs(drawn - 50000) < 200000 // config.SPATIAL_ORDER_STRATA + 1000
     assert v._sph.last_render_mass_scale == pytest.approx(200000 / drawn, rel=1e-12)
     partial = v._sph.get_image()             # scaled by N/N_drawn
     ratio = partial[..., 0].sum() / full[..., 0].sum()
@@ -369,15 +370,15 @@ def test_cell_progression_multi_range_blocks():
 
 def test_first_interactive_block_is_a_whole_stratum():
     """A device-resident snapshot of 5e6 particles: the first interactive block (1e5 requested) is rounded up to
-    one stratum (~1.6e5), and that preview -- scaled by N/N_drawn -- carries the mass of the full image to 2 %,
+    one stratum (5e6 / config.SPATIAL_ORDER_STRATA), and that preview -- scaled by N/N_drawn -- carries the mass of the full image to 2 %,
     which a spatially compact index range would not."""
     v = topsy_amd.synthetic_on_device(5_000_000, render_resolution=256)
     v.scale = 200.0
     full = v._sph.get_image().copy()
     rp = v._sph._render_progression
     bounds = v.particle_buffers.block_boundaries
-    assert len(bounds) == 33 and (np.diff(bounds) > 0).all() and bounds[-1] == 5_000_000
-    assert abs(np.diff(bounds) / (5_000_000 / 32) - 1.0).max() < 0.02        # uniform random strata
+    assert len(bounds) == config.SPATIAL_ORDER_STRATA + 1 and (np.diff(bounds) > 0).all() and bounds[-1] == 5_000_000
+    assert abs(np.diff(bounds) / (5_000_000 / config.SPATIAL_ORDER_STRATA) - 1.0).max() < 0.02        # uniform random strata
     timer = v._sph._render_timer
     real_add = timer.add_block
     timer.add_block = lambda ms, wall_seconds=None: real_add(40.0)           # one block per frame

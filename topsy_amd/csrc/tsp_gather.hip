@@ -467,6 +467,7 @@ static int launch_huge2(tsp_context *ctx, TileArgs ta, long long n_huge) {
         if (n_huge < (1ll << 16)) split = std::max(32, (int)((long long)split * n_huge >> 16));      // a small render block: in proportion
         else if (HR == 32 && NACC == 1) split = n_huge >= 2000000 ? split : (n_huge >= 1000000 ? (split * 3) / 4 : split / 2);
         else if (HR == 16 && NACC == 1) split = std::max(1, split / 2);      // (64x16 strips serve < 2.5e5 records: 32 / 64 / 128 per 128x32 tile -> 2.64 / 2.18 / 2.38 ms at 1.5e5)
+        else if (HR == 16 && NACC == 2 && n_huge < 1000000) split = std::max(1, split / 2);      // two channels, 3.4e5 records: 64 / 128 / 192 / 256 -> 4.49 / 5.16 / 6.49 / 8.16 ms
     }
     split = (int)std::min<long long>(split, std::max<long long>(batches, 1));
     ta.split = split;

@@ -133,7 +133,7 @@ struct tsp_context {
     int64_t huge_band_budget = 6ll << 30;   // bytes the band bins of the huge records may take (n_bands x n_huge records); above it kernel H2 scans one list
     int huge_variant = 1;             // kernel H2's strip shape / occupancy: 1 = auto (density: 64x32 strips at 8 waves/SIMD from 7e5 records, 64x16 below; two channels 64x16 at 7; rgb at 5), 2 / 4-7 = A/B builds
     int mid_split = 128, huge_split = 0;  // workgroups per image tile of kernels M / H2 (0 = auto)
-    int reorder_interleave = 1;     // tsp_reorder_spatial transposes every 512-particle block 64 x 8 (lane decorrelation for kernel S, tsp_data.hip)
+    int reorder_interleave = 2;     // tsp_reorder_spatial's arrangement inside every 512-particle block: 0 Morton order, 1 transposed 64 x 8, 2 by descending smoothing length (tsp_data.hip)
     int stream_blocks_per_cu = 100;  // kernel S grid bound: ~10 chunks per workgroup at 1e8 particles balances dense and sparse chunks
     bool chunk_cull = true;           // chunks (512 consecutive particles) whose bounds lie outside the view are skipped by kernel S
                                       // unread: pays with a load-time spatial order (tsp_reorder_spatial); identical results

@@ -25,13 +25,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "tsp_pipeline.h"
-
-#ifndef TSP_S_PAIRMERGE
-#define TSP_S_PAIRMERGE 0      // experiment: kernel S sums lane pairs that hit one pixel before the LDS atomic (measured: see DESIGN.md)
-#endif
 
 namespace tsp {
 
@@ -111,6 +108,7 @@ struct StreamArgs {
 };
 
 static_assert(CHUNK == BOUNDS_BLOCK, "block bounds are kept per chunk-sized block");
+constexpr int T23_FLOATS = 17 * 17 + 9 * 9;      // kernel S's LDS copy of mip levels 2 and 3, zero-padded (see the kernel)
 
 // ---------------------------------------------------------------------------------------------
 // chunk culling: which chunks can reach the view at all
@@ -244,7 +242,10 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
     constexpr int WIN = WinSize<WC>::value;
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
     double *win = smem_d;                                            // [WC][WIN*WIN]
-    float *T23 = reinterpret_cast<float *>(win + WC * WIN * WIN);    // mip levels 2 (16x16) and 3 (8x8): 320 floats
+    // mip levels 2 (16 x 16) and 3 (8 x 8), each padded with one ZERO row and one ZERO column (17 x 17 and 9 x 9 floats): what a
+    // lane reads for a pixel its footprint does not cover (phase 4)
+    float *T23 = reinterpret_cast<float *>(win + WC * WIN * WIN);
+    constexpr int T23_L3 = 17 * 17;
     __shared__ unsigned s_red[SWAVES][2], s_mbb[SWAVES][2];
     __shared__ int s_cnt[SWAVES];
     __shared__ long long s_base[2];
@@ -268,7 +269,12 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         if (c_begin >= c_end) return;
         const float *mips = ap->mips;
         for (int i = tid; i < WC * WIN * WIN; i += SBLOCK) win[i] = 0.0;
-        for (int i = tid; i < 320; i += SBLOCK) T23[i] = mips[5120 + i];
+        for (int i = tid; i < T23_FLOATS; i += SBLOCK) {
+            float t = 0.0f;
+            if (i < 17 * 17) { const int r = i / 17, c = i - r * 17; if (r < 16 && c < 16) t = mips[5120 + r * 16 + c]; }
+            else { const int q = i - 17 * 17, r = q / 9, c = q - r * 9; if (r < 8 && c < 8) t = mips[5376 + r * 8 + c]; }
+            T23[i] = t;
+        }
     }
     __syncthreads();
 
@@ -527,7 +533,14 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
             const bool lvl2 = PP[k] > P_L2;
             const float nf = lvl2 ? 16.0f : 8.0f;
             const int nm1 = lvl2 ? 15 : 7;
-            unsigned pk_lo = 0u, pk_hi = 0u;          // texel column of footprint column c: 4 bits each
+            // Texel column of footprint column c, 5 bits each, six per register.  A column this lane does not cover (c >= nx; every
+            // column of a lane that rasterises nothing) points at the ZERO column of the padded level, a row it does not cover at the
+            // zero row: the texel read is then exactly 0 and the one test `texel != 0` below -- there anyway, because the corner
+            // texels of the kernel image are 0 -- masks the lane.  (Until round 5 every pixel step combined a row mask, a column
+            // mask and that test: ~7 scalar instructions per step, with the sixteen column masks spilled into VGPR lanes.)
+            const unsigned zc = lvl2 ? 16u : 8u;
+            const unsigned zc6 = zc * 0x2108421u;     // the zero column in all six fields
+            unsigned pk[3] = {zc6, zc6, zc6};
             const float x0f = (float)ilo + 0.5f;      // centre of the first covered column ((float)(ilo + c) + 0.5f == x0f + c exactly)
             int maxnx = 0;
 #pragma unroll
@@ -536,22 +549,22 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                 maxnx = ci + 1;
                 const float dx = (x0f + (float)ci) - pcx[k];
                 const int tx = clampi((int)__builtin_floorf(((dx + half) * ip) * nf), 0, nm1);
-                if (ci < 8) pk_lo |= (unsigned)tx << (4 * (ci & 7)); else pk_hi |= (unsigned)tx << (4 * (ci & 7));
+                pk[ci / 6] ^= ((ci < nx) ? ((unsigned)tx ^ zc) : 0u) << (5 * (ci % 6));
             }
             const float y0f = (float)jlo + 0.5f;
-            const float *lut = T23 + (lvl2 ? 0 : 256);
-            const int lstride = lvl2 ? 16 : 8;
+            const float *lut = T23 + (lvl2 ? 0 : T23_L3);
+            const int lstride = lvl2 ? 17 : 9;
             double *wbase = win + (jlo - woy) * WIN + (ilo - wox);
             if (MODE != TSP_MODE_RGB && WC == 1 && maxnx == 1) {
                 // Every footprint of this wave is one pixel COLUMN wide: the dense core of the snapshot, where thousands of
-                // sub-pixel particles share a pixel and neighbouring lanes (load-time Morton order) mostly hit the SAME
-                // pixel -- a same-address ds_add_f64 costs ~11 clk per extra lane (most of such a wave's lanes draw nothing:
-                // a footprint narrower than a pixel rarely covers a pixel centre).  When they are single pixels, the lanes
-                // that hit one pixel are summed across the wave first (DPP tree) and one lane issues the one atomic.
+                // sub-pixel particles share a pixel and the lanes of a step mostly hit the SAME pixel -- a same-address
+                // ds_add_f64 costs ~11 clk per extra lane (most of such a wave's lanes draw nothing: a footprint narrower than a
+                // pixel rarely covers a pixel centre).  When they are single pixels, the lanes that hit one pixel are summed
+                // across the wave first (DPP tree) and one lane issues the one atomic.
                 if (__ballot(act && ny != 1) == 0ull) {
                     const float dy = y0f - pcy[k];
                     const int ty = clampi((int)__builtin_floorf(((dy + half) * ip) * nf), 0, nm1);
-                    const float kv = act ? lut[ty * lstride + (int)(pk_lo & 15u)] : 0.0f;
+                    const float kv = act ? lut[ty * lstride + (int)(pk[0] & 31u)] : 0.0f;
                     const float val = kv * w0[k];
                     const int key = (int)(wbase - win);
                     unsigned long long todo = __ballot(act && val != 0.0f);
@@ -581,59 +594,43 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                 if (__ballot(rowact) == 0ull) break;
                 const float dy = (y0f + (float)r) - pcy[k];
                 const int ty = clampi((int)__builtin_floorf(((dy + half) * ip) * nf), 0, nm1);
-                const float *lrow = lut + ty * lstride;
-                const int nxr = rowact ? nx : 0;      // columns of this lane in this row
+                const float *lrow = lut + (rowact ? ty : (int)zc) * lstride;
                 double *wrow = wbase + r * WIN;
+                // a group = six footprint columns (one register of texel fields); its pixel steps are unrolled for 2, 4 or 6
+                // columns -- the wave's widest footprint rounded up to even -- with no test between them: a column beyond the
+                // wave's widest footprint reads the zero column in every lane
+                auto group = [&](int g, auto nc_c) {
+                    constexpr int NC = decltype(nc_c)::value;
+                    float v[NC];
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    if (8 * g >= maxnx) break;
-                    const unsigned pk = g ? pk_hi : pk_lo;
-                    float v[8];
+                    for (int j = 0; j < NC; ++j) v[j] = lrow[(pk[g] >> (5 * j)) & 31u];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        v[j] = 0.0f;
-                        if (8 * g + j < maxnx) v[j] = lrow[(pk >> (4 * j)) & 15u];      // (fields beyond nx are 0: a valid address)
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int ci = 8 * g + j;
-                        if (ci >= maxnx) break;
+                    for (int j = 0; j < NC; ++j) {
+                        const int ci = 6 * g + j;
 #ifdef TSP_S_DEBUG       // analysis build: lane slots the raster loop spends (64 per executed pixel step), reported as the M fragment count
                         if (count_frag && lane == 0) dbg_slots += 64ull;
 #endif
-#if TSP_S_PAIRMERGE
-                        bool pm_act = false; float pm_val = 0.0f; int pm_key = 0;
-#endif
-                        if (ci < nxr) {
-                            double *d = wrow + ci;
-                            if (MODE == TSP_MODE_RGB) {
+                        double *d = wrow + ci;
+                        if (MODE == TSP_MODE_RGB) {      // (the count channel also counts the fragments whose texel is exactly 0)
+                            if (rowact && ci < nx) {
                                 latomic_add(d, v[j] * w0[k]); latomic_add(d + WIN * WIN, v[j] * w1[k]);
                                 latomic_add(d + 2 * WIN * WIN, v[j] * w2[k]); latomic_add(d + 3 * WIN * WIN, 1.0f);
-                            } else if (v[j] != 0.0f) {      // corner texels are exactly 0: adding +-0 changes nothing
-                                const float val = v[j] * w0[k];
-#if TSP_S_PAIRMERGE
-                                if (WC == 1) { pm_act = true; pm_val = val; pm_key = (int)(d - win); }
-                                else
-#endif
-                                {
-                                latomic_add(d, val);
-                                if (WC > 1) latomic_add(d + WIN * WIN, val * w1[k]);
-                                }
                             }
+                        } else if (v[j] != 0.0f) {       // covered, and not one of the kernel image's zero corner texels
+                            const float val = v[j] * w0[k];
+                            latomic_add(d, val);
+                            if (WC > 1) latomic_add(d + WIN * WIN, val * w1[k]);
                         }
-#if TSP_S_PAIRMERGE
-                        if (WC == 1 && MODE != TSP_MODE_RGB) {
-                            // experiment: two neighbouring lanes (2 i, 2 i + 1) that hit the SAME pixel
-                            // in this step are summed first (v_mov_dpp quad_perm:[1,0,3,2]) and the even lane issues one atomic
-                            const int key = pm_act ? pm_key : (-1 - lane);
-                            const int okey = __builtin_amdgcn_mov_dpp(key, 0xb1, 0xf, 0xf, true);
-                            const float oval = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(pm_val), 0xb1, 0xf, 0xf, true));
-                            const bool same = key == okey;
-                            if (pm_act && !(same && (lane & 1))) latomic_add(win + pm_key, same ? pm_val + oval : pm_val);
-                            pm_act = false; pm_val = 0.0f;
-                        }
-#endif
                     }
+                };
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const int nc = maxnx - 6 * g;                // (wave-uniform)
+                    if (nc <= 0) break;
+                    if (g == 2 || nc <= 4) {                     // (group 2 holds columns 12 .. 15)
+                        if (nc <= 2) group(g, std::integral_constant<int, 2>());
+                        else group(g, std::integral_constant<int, 4>());
+                    } else group(g, std::integral_constant<int, 6>());
                 }
             }
             if (act) {
@@ -701,6 +698,9 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
 // ---------------------------------------------------------------------------------------------
 
 constexpr int MT = 512;              // threads per workgroup of kernel M (8 waves share tile + LUT)
+#ifndef TSP_M_BRANCHFREE
+#define TSP_M_BRANCHFREE 1
+#endif
 
 // LUT quadrants: the kernel image is a radial function sampled on a grid symmetric about its centre, so every mip level
 // equals its mirror images bit for bit (checked at upload, tsp_set_kernel_mips).  Kernel M then keeps only the top-left
@@ -825,6 +825,65 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                     const int pk = __builtin_amdgcn_readlane(packed, src);
                     const int ilo = pk & 63, ihi = (pk >> 6) & 63, jlo = (pk >> 12) & 63, jhi = (pk >> 18) & 63, lvl = pk >> 24;
                     const int n = 64 >> lvl, toff = QUAD ? mipq_offset(lvl) : mip_offset(lvl), tstride = QUAD ? (n >> 1) : n;
+                  if constexpr (TSP_M_BRANCHFREE && MODE != TSP_MODE_RGB) {
+                    // Branch-free 8 x 8 stepping (round 5; density 16.7 -> 15.4 ms at 1e9 particles, rgb -- three selects and atomics per step on
+                    // 16-row tiles -- 13.7 -> 14.0 at config 4: rgb keeps the masked form below).  Per 8-row block rb this lane's LUT row (byte offset), its row of the LDS
+                    // tile -- wrapped into the tile with `& (MTILE_H - 1)`, so a lane below the footprint's last row still holds a
+                    // valid address -- and the lane mask "my row is covered" are formed once per footprint.  A step then runs with
+                    // the whole wave: the texel is read, multiplied, SELECTED to +0 in the lanes the footprint does not cover (x + 0
+                    // is x: an uncovered lane adds nothing), converted and added -- no exec-mask save / branch / restore per block
+                    // (those were half of this kernel's 5.4e9 scalar instructions at 1e9 particles), and the LUT reads of a column
+                    // step are issued together and awaited once.  Every (column step, row block) has a covered lane, so no LDS
+                    // instruction is issued that the masked form would have skipped.
+                    constexpr int NRB_MAX = MTILE_H / 8;
+                    int trowB[NRB_MAX], rowA[NRB_MAX];
+                    bool rowok[NRB_MAX];                                    // (lane masks in scalar registers)
+#pragma unroll
+                    for (int rb = 0; rb < NRB_MAX; ++rb) {
+                        const int j = jlo + 8 * rb + ly;
+                        const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
+                        int ty = nearest_index((dy + q_half) * q_invP, n);
+                        if (QUAD) ty = min(ty, n - 1 - ty);
+                        trowB[rb] = (toff + ty * tstride) * 4;
+                        rowA[rb] = (j & (MTILE_H - 1)) * (MSTR * 8);
+                        rowok[rb] = j <= jhi;
+                    }
+                    const int nrb = ((jhi - jlo) >> 3) + 1;                 // row blocks the footprint touches in this tile (wave-uniform)
+                    const char *Tb = reinterpret_cast<const char *>(T);
+                    char *tileb = reinterpret_cast<char *>(tile);
+                    auto draw = [&](auto nrb_c) {
+                        constexpr int NRB = decltype(nrb_c)::value;
+                        for (int ib = ilo; ib <= ihi; ib += 8) {
+                            const int i = ib + lx;
+                            const float dx = ((float)(tx0 + i) + 0.5f) - q_pcx;
+                            int tx = nearest_index((dx + q_half) * q_invP, n);
+                            if (QUAD) tx = min(tx, n - 1 - tx);
+                            const bool colok = i <= ihi;
+                            float kv[NRB];
+#pragma unroll
+                            for (int rb = 0; rb < NRB; ++rb) kv[rb] = *reinterpret_cast<const float *>(Tb + trowB[rb] + tx * 4);
+#pragma unroll
+                            for (int rb = 0; rb < NRB; ++rb) {
+                                const bool ok = colok && rowok[rb];
+                                double *d = reinterpret_cast<double *>(tileb + rowA[rb] + i * 8);
+                                // the select acts on the float32 product (one v_cndmask), pinned before the conversion
+                                auto pick = [&](float v) { float r = ok ? v : 0.0f; asm volatile("" : "+v"(r)); return r; };
+                                if (MODE == TSP_MODE_RGB) {     // the counter channel is summed by add_rect_counts()
+                                    latomic_add(d, pick(kv[rb] * w0)); latomic_add(d + MTILE_H * MSTR, pick(kv[rb] * w1));
+                                    latomic_add(d + 2 * MTILE_H * MSTR, pick(kv[rb] * w2));
+                                } else {
+                                    const float val = kv[rb] * w0;
+                                    latomic_add(d, pick(val));
+                                    if (WC > 1) latomic_add(d + MTILE_H * MSTR, pick(val * w1));
+                                }
+                            }
+                        }
+                    };
+                    if (NRB_MAX == 4 && nrb == 4) draw(std::integral_constant<int, NRB_MAX>());
+                    else if (NRB_MAX >= 3 && nrb == 3) draw(std::integral_constant<int, (NRB_MAX >= 3 ? 3 : 1)>());
+                    else if (nrb == 2) draw(std::integral_constant<int, 2>());
+                    else draw(std::integral_constant<int, 1>());
+                  } else {
                     // texel row of this lane's pixel row in each 8-row block of the footprint (the tile is 32 rows: <= 4 blocks)
                     int trow[MTILE_H / 8];
 #pragma unroll
@@ -861,6 +920,7 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                             }
                         }
                     }
+                  }
                     if (a.count_frag && lane == 0) n_frag += (unsigned long long)((ihi - ilo + 1) * (jhi - jlo + 1));
                 }
             }
@@ -1051,7 +1111,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     const bool second_channel = (MODE == TSP_MODE_DEPTH) || (MODE == TSP_MODE_RGB) || (ctx->p.q != nullptr && ctx->use_quantity);
     const int WCr = (MODE == TSP_MODE_RGB) ? 4 : (second_channel ? 2 : 1);
     const int WIN = (WCr == 1) ? WinSize<1>::value : WinSize<C>::value;
-    const size_t smem_s = (size_t)WCr * WIN * WIN * sizeof(double) + 320 * sizeof(float);
+    const size_t smem_s = (size_t)WCr * WIN * WIN * sizeof(double) + T23_FLOATS * sizeof(float);
     constexpr int WCM = (MODE == TSP_MODE_RGB) ? 3 : C;      // LDS tile channels of kernel M (rgb: values only)
     const int mth = mtile_h(WCr == 1 ? 1 : WCM);
     // quadrant tables pay where LDS limits the occupancy: rgb (three channels: 2 -> 4 workgroups per CU, 21.0 -> 17.1 ms);
@@ -1060,8 +1120,8 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     const size_t smem_m = (size_t)(WCr == 1 ? 1 : WCM) * mth * MSTR * sizeof(double) + (quad ? MIPQ_TOTAL : MIP_TOTAL) * sizeof(float) + (size_t)ctx->debug_extra_lds;
     const int mtiles_y = (ctx->R + mth - 1) / mth;
     if (!(ctx->kernel_attr_done & (1u << MODE))) {
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WinSize<C>::value * WinSize<C>::value * sizeof(double) + 1280)));
-        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WinSize<1>::value * WinSize<1>::value * sizeof(double) + 1280)));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WinSize<C>::value * WinSize<C>::value * sizeof(double) + T23_FLOATS * sizeof(float))));
+        TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WinSize<1>::value * WinSize<1>::value * sizeof(double) + T23_FLOATS * sizeof(float))));
         ctx->kernel_attr_done |= 1u << MODE;
         ctx->mid_attr_extra[MODE] = -1;
     }
