@@ -18,7 +18,7 @@ if reorder: ctx.reorder_spatial(reorder, 1337)
 print(f"n={n:.3g} generate {tg:.2f}s reorder {time.time()-t:.2f}s")
 for k, v in opts.items(): ctx.set_option(k, int(v))
 M = np.eye(4, dtype=np.float32); M[:3, :3] /= scale; M[2, :] = [0, 0, 0.5 / scale, 0.5]
-md = _native.MODE_RGB if mode == "rgb" else _native.MODE_WEIGHTED
+md = _native.MODE_RGB if mode == "rgb" else (_native.MODE_DEPTH if mode == "depth" else _native.MODE_WEIGHTED)
 for f in range(frames):
     ms = ctx.render(M, 1.0 / scale, mode=md); st = ctx.stats()
     print(f"frame {f}: total {ms:.3f} ms  S {st['ms_stream']:.3f}  M {st['ms_mid']:.3f}  H2 {st['ms_huge']:.3f}  small/mid/huge/cull {st['n_small']}/{st['n_mid']}/{st['n_huge']}/{st['n_culled']}")

@@ -701,6 +701,9 @@ constexpr int MT = 512;              // threads per workgroup of kernel M (8 wav
 #ifndef TSP_M_BRANCHFREE
 #define TSP_M_BRANCHFREE 1
 #endif
+// rows of one channel of kernel M's LDS tile: with the branch-free stepping of a density render a lane up to 7 rows below the
+// tile's last row adds +0 to "its" pixel, so the tile carries 7 rows nobody reads
+constexpr int mtile_rows(int mode, int wc) { return mtile_h(wc) + ((TSP_M_BRANCHFREE && mode != TSP_MODE_RGB && wc == 1) ? 7 : 0); }
 
 // LUT quadrants: the kernel image is a radial function sampled on a grid symmetric about its centre, so every mip level
 // equals its mirror images bit for bit (checked at upload, tsp_set_kernel_mips).  Kernel M then keeps only the top-left
@@ -718,9 +721,10 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
     constexpr int MTILE_H = mtile_h(WC);
+    constexpr int MROWS = mtile_rows(MODE, WC);                              // LDS rows per channel: the tile + (branch-free stepping) 7 rows that only ever receive +0
     extern __shared__ __attribute__((aligned(16))) double smem_d[];
-    double *tile = smem_d;                                                   // [WC][MTILE_H][MSTR]
-    float *T = reinterpret_cast<float *>(tile + WC * MTILE_H * MSTR);        // mip pyramid: 5440 floats, or 1360 (quadrants)
+    double *tile = smem_d;                                                   // [WC][MROWS][MSTR]
+    float *T = reinterpret_cast<float *>(tile + WC * MROWS * MSTR);          // mip pyramid: 5440 floats, or 1360 (quadrants)
     __shared__ long long s_seg_off[MT];
     __shared__ int s_seg_cnt[MT];
     __shared__ int s_wcnt[MT / 64];
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
     } else {
         for (int i = tid; i < MIP_TOTAL; i += MT) T[i] = a.mips[i];
     }
-    for (int i = tid; i < WC * MTILE_H * MSTR; i += MT) tile[i] = 0.0;
+    for (int i = tid; i < WC * MROWS * MSTR; i += MT) tile[i] = 0.0;
     __syncthreads();
     const int lx = lane & 7, ly = lane >> 3;
     unsigned long long n_frag = 0;
@@ -825,16 +829,71 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                     const int pk = __builtin_amdgcn_readlane(packed, src);
                     const int ilo = pk & 63, ihi = (pk >> 6) & 63, jlo = (pk >> 12) & 63, jhi = (pk >> 18) & 63, lvl = pk >> 24;
                     const int n = 64 >> lvl, toff = QUAD ? mipq_offset(lvl) : mip_offset(lvl), tstride = QUAD ? (n >> 1) : n;
-                  if constexpr (TSP_M_BRANCHFREE && MODE != TSP_MODE_RGB) {
-                    // Branch-free 8 x 8 stepping (round 5; density 16.7 -> 15.4 ms at 1e9 particles, rgb -- three selects and atomics per step on
-                    // 16-row tiles -- 13.7 -> 14.0 at config 4: rgb keeps the masked form below).  Per 8-row block rb this lane's LUT row (byte offset), its row of the LDS
-                    // tile -- wrapped into the tile with `& (MTILE_H - 1)`, so a lane below the footprint's last row still holds a
-                    // valid address -- and the lane mask "my row is covered" are formed once per footprint.  A step then runs with
-                    // the whole wave: the texel is read, multiplied, SELECTED to +0 in the lanes the footprint does not cover (x + 0
-                    // is x: an uncovered lane adds nothing), converted and added -- no exec-mask save / branch / restore per block
-                    // (those were half of this kernel's 5.4e9 scalar instructions at 1e9 particles), and the LUT reads of a column
-                    // step are issued together and awaited once.  Every (column step, row block) has a covered lane, so no LDS
-                    // instruction is issued that the masked form would have skipped.
+                  if constexpr (TSP_M_BRANCHFREE && MODE != TSP_MODE_RGB && WC == 1) {
+                    // Branch-free 8 x 8 stepping (round 5: density 16.7 -> 15.4 -> 15.1 ms at 1e9 particles; rgb -- three atomics per step on
+                    // 16-row tiles -- measured slower and keeps the masked form below).  Per 8-row block rb this lane's LUT row (byte
+                    // offset) and its WEIGHT are formed once per footprint: the footprint's weight where the lane's pixel row is covered,
+                    // +0 where it is not -- so a step multiplies, converts and adds with the whole wave, and a lane below the footprint's
+                    // last row adds +0 to its own pixel (x + 0 is x) of the tile, which carries MPAD extra rows for it.  No exec-mask
+                    // save / branch / restore per block (those were half of this kernel's 5.4e9 scalar instructions at 1e9 particles);
+                    // the LUT reads of a column step are issued together and awaited once; the LDS addresses of a step's row blocks
+                    // differ by immediates.  Only the LAST column step of a footprint can hold uncovered columns: it alone selects.
+                    constexpr int NRB_MAX = MTILE_H / 8;
+                    int trowB[NRB_MAX];
+                    float wv0[NRB_MAX], wv1[NRB_MAX];
+#pragma unroll
+                    for (int rb = 0; rb < NRB_MAX; ++rb) {
+                        const int j = jlo + 8 * rb + ly;
+                        const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
+                        int ty = nearest_index((dy + q_half) * q_invP, n);
+                        if (QUAD) ty = min(ty, n - 1 - ty);
+                        trowB[rb] = (toff + ty * tstride) * 4;
+                        wv0[rb] = (j <= jhi) ? w0 : 0.0f;
+                        wv1[rb] = (j <= jhi) ? w1 : 0.0f;       // (its own +0: val * w1 with val = 0 would be NaN for a non-finite quantity)
+                    }
+                    const int nrb = ((jhi - jlo) >> 3) + 1;                 // row blocks the footprint touches in this tile (wave-uniform)
+                    const char *Tb = reinterpret_cast<const char *>(T);
+                    char *rowp = reinterpret_cast<char *>(tile) + ((jlo + ly) * MSTR) * 8;      // this lane's pixel row of block 0
+                    auto draw = [&](auto nrb_c) {
+                        constexpr int NRB = decltype(nrb_c)::value;
+                        auto step = [&](int ib, auto partial_c) {
+                            constexpr bool PARTIAL = decltype(partial_c)::value;
+                            const int i = ib + lx;
+                            const float dx = ((float)(tx0 + i) + 0.5f) - q_pcx;
+                            int tx = nearest_index((dx + q_half) * q_invP, n);
+                            if (QUAD) tx = min(tx, n - 1 - tx);
+                            const bool colok = i <= ihi;
+                            float kv[NRB];
+#pragma unroll
+                            for (int rb = 0; rb < NRB; ++rb) kv[rb] = *reinterpret_cast<const float *>(Tb + trowB[rb] + tx * 4);
+                            double *dcol = reinterpret_cast<double *>(rowp + i * 8);
+#pragma unroll
+                            for (int rb = 0; rb < NRB; ++rb) {
+                                float val = kv[rb] * wv0[rb];
+                                float val1 = (WC > 1) ? val * wv1[rb] : 0.0f;       // canonical order (k w0) q in a covered row, 0 * 0 in an uncovered one
+                                if (PARTIAL) {      // the select acts on the float32 products, pinned before the conversions
+                                    val = colok ? val : 0.0f; asm volatile("" : "+v"(val));
+                                    if (WC > 1) { val1 = colok ? val1 : 0.0f; asm volatile("" : "+v"(val1)); }
+                                }
+                                double *d = dcol + rb * 8 * MSTR;
+                                latomic_add(d, val);
+                                if (WC > 1) latomic_add(d + MROWS * MSTR, val1);
+                            }
+                        };
+                        // (two channels on 16-row tiles: few steps per (footprint, tile) pair -- one loop that always selects measured
+                        // faster than the split: 1e7 weighted 2.05 against 2.34 ms)
+                        int ib = ilo;
+                        if (WC == 1) for (; ib + 7 <= ihi; ib += 8) step(ib, std::false_type());
+                        for (; ib <= ihi; ib += 8) step(ib, std::true_type());
+                    };
+                    if (NRB_MAX == 4 && nrb == 4) draw(std::integral_constant<int, NRB_MAX>());
+                    else if (NRB_MAX >= 3 && nrb == 3) draw(std::integral_constant<int, (NRB_MAX >= 3 ? 3 : 1)>());
+                    else if (nrb == 2) draw(std::integral_constant<int, 2>());
+                    else draw(std::integral_constant<int, 1>());
+                  } else if constexpr (TSP_M_BRANCHFREE && MODE != TSP_MODE_RGB) {
+                    // Two channels (16-row tiles, few steps per (footprint, tile) pair): the first branch-free form -- row and column
+                    // masks combined per step (one scalar AND), the products selected to +0, rows wrapped into the tile instead of
+                    // padding it -- measured faster than the form above here (1e7 weighted: 2.00 against 2.34 ms; masked: 2.06)
                     constexpr int NRB_MAX = MTILE_H / 8;
                     int trowB[NRB_MAX], rowA[NRB_MAX];
                     bool rowok[NRB_MAX];                                    // (lane masks in scalar registers)
@@ -869,12 +928,12 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                                 // the select acts on the float32 product (one v_cndmask), pinned before the conversion
                                 auto pick = [&](float v) { float r = ok ? v : 0.0f; asm volatile("" : "+v"(r)); return r; };
                                 if (MODE == TSP_MODE_RGB) {     // the counter channel is summed by add_rect_counts()
-                                    latomic_add(d, pick(kv[rb] * w0)); latomic_add(d + MTILE_H * MSTR, pick(kv[rb] * w1));
-                                    latomic_add(d + 2 * MTILE_H * MSTR, pick(kv[rb] * w2));
+                                    latomic_add(d, pick(kv[rb] * w0)); latomic_add(d + MROWS * MSTR, pick(kv[rb] * w1));
+                                    latomic_add(d + 2 * MROWS * MSTR, pick(kv[rb] * w2));
                                 } else {
                                     const float val = kv[rb] * w0;
                                     latomic_add(d, pick(val));
-                                    if (WC > 1) latomic_add(d + MTILE_H * MSTR, pick(val * w1));
+                                    if (WC > 1) latomic_add(d + MROWS * MSTR, pick(val * w1));
                                 }
                             }
                         }
@@ -910,12 +969,12 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                                 const float kv = T[trow[rb] + tx];
                                 double *d = dcol + rb * 8 * MSTR;
                                 if (MODE == TSP_MODE_RGB) {     // the counter channel is summed by add_rect_counts()
-                                    latomic_add(d, kv * w0); latomic_add(d + MTILE_H * MSTR, kv * w1);
-                                    latomic_add(d + 2 * MTILE_H * MSTR, kv * w2);
+                                    latomic_add(d, kv * w0); latomic_add(d + MROWS * MSTR, kv * w1);
+                                    latomic_add(d + 2 * MROWS * MSTR, kv * w2);
                                 } else {      // (skipping the exactly-zero corner texels lane by lane measured slower: 5.5 -> 6.0 ms)
                                     const float val = kv * w0;
                                     latomic_add(d, val);
-                                    if (WC > 1) latomic_add(d + MTILE_H * MSTR, val * w1);
+                                    if (WC > 1) latomic_add(d + MROWS * MSTR, val * w1);
                                 }
                             }
                         }
@@ -934,7 +993,7 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
             if (gx < R && gy < R) {
 #pragma unroll
                 for (int c = 0; c < WC; ++c) {
-                    const double v = tile[c * MTILE_H * MSTR + wy * MSTR + wx];
+                    const double v = tile[c * MROWS * MSTR + wy * MSTR + wx];
                     if (v != 0.0) gatomic_add(a.img + ((size_t)gy * R + gx) * C + c, v);
                 }
             }
@@ -1117,7 +1176,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     // quadrant tables pay where LDS limits the occupancy: rgb (three channels: 2 -> 4 workgroups per CU, 21.0 -> 17.1 ms);
     // a density render already fits three workgroups and measured slower with four (7.6 vs 7.2 ms: LDS-atomic-bound)
     const bool quad = ctx->lut_mirror_symmetric && MODE == TSP_MODE_RGB;
-    const size_t smem_m = (size_t)(WCr == 1 ? 1 : WCM) * mth * MSTR * sizeof(double) + (quad ? MIPQ_TOTAL : MIP_TOTAL) * sizeof(float) + (size_t)ctx->debug_extra_lds;
+    const size_t smem_m = (size_t)(WCr == 1 ? 1 : WCM) * mtile_rows(MODE, WCr == 1 ? 1 : WCM) * MSTR * sizeof(double) + (quad ? MIPQ_TOTAL : MIP_TOTAL) * sizeof(float) + (size_t)ctx->debug_extra_lds;
     const int mtiles_y = (ctx->R + mth - 1) / mth;
     if (!(ctx->kernel_attr_done & (1u << MODE))) {
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WinSize<C>::value * WinSize<C>::value * sizeof(double) + T23_FLOATS * sizeof(float))));
@@ -1127,7 +1186,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     }
     if (ctx->mid_attr_extra[MODE] != ctx->debug_extra_lds) {
         // the dynamic-LDS limit of kernel M follows the debug_extra_lds option (a measurement aid that lowers its occupancy)
-        const int lds_m = (int)((size_t)C * 32 * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float)) + ctx->debug_extra_lds;
+        const int lds_m = (int)((size_t)C * (32 + 7) * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float)) + ctx->debug_extra_lds;
         const void *fns[4] = {(const void *)splat_mid_kernel<MODE, WCM, false>, (const void *)splat_mid_kernel<MODE, 1, false>,
                               (const void *)splat_mid_kernel<MODE, WCM, true>, (const void *)splat_mid_kernel<MODE, 1, true>};
         for (const void *fn : fns) {
