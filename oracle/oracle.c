@@ -207,7 +207,10 @@ static inline void particle_weights(float *w, int mode, proj_t pr, float hp, con
  * out: R*R*C float32 (C = 2 or 4).  accumulate != 0 adds to `out` instead of overwriting.
  * Returns the total fragment count. */
 #ifndef ORC_BATCH
-#define ORC_BATCH 10000000      /* particles per batch of the tile-parallel splat (bounds the (particle, tile) entry list) */
+#define ORC_BATCH 50000000      /* most particles per batch of the tile-parallel splat */
+#endif
+#ifndef ORC_ENTRY_BUDGET
+#define ORC_ENTRY_BUDGET 200000000LL   /* most (particle, tile) entries per batch (8 bytes each): a batch ends early when wide footprints fill it */
 #endif
 
 long orc_splat_rule(long n, const float *x, const float *y, const float *z, const float *h,
@@ -240,8 +243,8 @@ long orc_splat_rule(long n, const float *x, const float *y, const float *z, cons
         nsel += end - beg;
     }
     roff[nranges] = nsel;
-    /* The drawing sequence is processed in BATCHES of at most ORC_BATCH particles (the per-(particle, tile) entry list of
-     * one batch stays bounded: a 1000-px footprint spans ~1000 tiles of 32 x 32 px).  Every tile's terms are still added in
+    /* The drawing sequence is processed in BATCHES of at most ORC_BATCH particles and ORC_ENTRY_BUDGET (particle, tile) entries
+     * (a 1000-px footprint spans ~1000 tiles of 32 x 32 px: the entry list of a batch stays bounded whatever the footprints).  Every tile's terms are still added in
      * drawing order into ONE float64 accumulator image that lives across the batches, so the sequence of float64 additions per
      * pixel -- and with it the result, bit for bit -- is that of a single pass (and independent of the thread count).
      * A failed allocation returns -1 (the Python wrapper raises MemoryError). */
@@ -255,8 +258,9 @@ long orc_splat_rule(long n, const float *x, const float *y, const float *z, cons
     int64_t entries_cap = 0;
     long total_frag = 0;
     int failed = (!rbeg || !box || !tcount || !tstart || !accimg);
-    for (int64_t f0 = 0; f0 < nsel && !failed; f0 += batch_cap) {
-        const int64_t nb = (nsel - f0 < batch_cap) ? nsel - f0 : batch_cap;
+    int64_t nb = 0;
+    for (int64_t f0 = 0; f0 < nsel && !failed; f0 += nb) {
+        nb = (nsel - f0 < batch_cap) ? nsel - f0 : batch_cap;
         /* pass A: tile rectangle of every particle of the batch (x0 > x1 = draws nothing) */
 #pragma omp parallel for schedule(static) num_threads(nthreads)
         for (int64_t k = 0; k < nb; ++k) {
@@ -276,6 +280,15 @@ long orc_splat_rule(long n, const float *x, const float *y, const float *z, cons
                 }
             }
             box[k] = q;
+        }
+        {   /* the batch ends where its entry list would exceed the budget (at least one particle) */
+            int64_t e = 0, k = 0;
+            for (; k < nb; ++k) {
+                const box_t q = box[k];
+                if (q.x0 <= q.x1) e += (int64_t)(q.x1 - q.x0 + 1) * (q.y1 - q.y0 + 1);
+                if (e > ORC_ENTRY_BUDGET && k > 0) break;
+            }
+            nb = k;
         }
         /* pass B: per tile, the positions (in the drawing sequence) of the batch's particles that reach it, ascending.
          * One thread per tile ROW scans the boxes twice (count, fill): no atomics, order preserved. */
