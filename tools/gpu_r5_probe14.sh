@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 5: kernel M's padded LUT rows again, now that the branch-free stepping has made the LDS pipe its limit (A/B: "nopad" = natural strides)
+cd $GRAFT_REPO_ROOT
+S="1.25e8 ntotal=1e9 first=375000000"
+for a in "1e9 reorder=32" "$S reorder=8" "1e8 reorder=8" "1e7 reorder=8" "1e7 reorder=8 mode=weighted" "5e7 reorder=8 mode=rgb R=2048" "1.25e8 reorder=8 scale=50"; do
+  tools/gpu_ab.sh "- nopad" $a 2>&1 | grep -E "===|frame [34]" | cut -c 1-110
+done

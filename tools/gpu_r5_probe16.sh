@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 5: kernel M prepares only the row blocks a footprint touches, shifts instead of 32-bit multiplies (product) against the previous commit ("m2")
+cd $GRAFT_REPO_ROOT
+S="1.25e8 ntotal=1e9 first=375000000"
+for a in "1e9 reorder=32" "$S reorder=8" "1e8 reorder=8" "1e7 reorder=8" "1e7 reorder=8 mode=weighted" "5e7 reorder=8 mode=rgb R=2048" "1.25e8 reorder=8 scale=50" "1.25e8 reorder=8 hcap=8"; do
+  tools/gpu_ab.sh "- m2" $a 2>&1 | grep -E "===|frame [34]" | cut -c 1-110
+done

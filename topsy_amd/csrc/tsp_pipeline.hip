@@ -564,7 +564,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                 if (__ballot(act && ny != 1) == 0ull) {
                     const float dy = y0f - pcy[k];
                     const int ty = clampi((int)__builtin_floorf(((dy + half) * ip) * nf), 0, nm1);
-                    const float kv = act ? lut[ty * lstride + (int)(pk[0] & 31u)] : 0.0f;
+                    const float kv = act ? lut[__mul24(ty, lstride) + (int)(pk[0] & 31u)] : 0.0f;
                     const float val = kv * w0[k];
                     const int key = (int)(wbase - win);
                     unsigned long long todo = __ballot(act && val != 0.0f);
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                 if (__ballot(rowact) == 0ull) break;
                 const float dy = (y0f + (float)r) - pcy[k];
                 const int ty = clampi((int)__builtin_floorf(((dy + half) * ip) * nf), 0, nm1);
-                const float *lrow = lut + (rowact ? ty : (int)zc) * lstride;
+                const float *lrow = lut + __mul24(rowact ? ty : (int)zc, lstride);      // (24-bit multiply: full rate; v_mul_lo_u32 runs at a quarter)
                 double *wrow = wbase + r * WIN;
                 // a group = six footprint columns (one register of texel fields); its pixel steps are unrolled for 2, 4 or 6
                 // columns -- the wave's widest footprint rounded up to even -- with no test between them: a column beyond the
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                     const float w2 = (NW == 2) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gw2), src)) : 0.0f;
                     const int pk = __builtin_amdgcn_readlane(packed, src);
                     const int ilo = pk & 63, ihi = (pk >> 6) & 63, jlo = (pk >> 12) & 63, jhi = (pk >> 18) & 63, lvl = pk >> 24;
-                    const int n = 64 >> lvl, toff = QUAD ? mipq_offset(lvl) : mip_offset(lvl), tstride = QUAD ? (n >> 1) : n;
+                    const int n = 64 >> lvl, toff = QUAD ? mipq_offset(lvl) : mip_offset(lvl), tshift = QUAD ? 5 - lvl : 6 - lvl;      // LUT row stride = 1 << tshift
                   if constexpr (TSP_M_BRANCHFREE && MODE != TSP_MODE_RGB && WC == 1) {
                     // Branch-free 8 x 8 stepping (round 5: density 16.7 -> 15.4 -> 15.1 ms at 1e9 particles; rgb -- three atomics per step on
                     // 16-row tiles -- measured slower and keeps the masked form below).  Per 8-row block rb this lane's LUT row (byte
@@ -839,23 +839,25 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                     // the LUT reads of a column step are issued together and awaited once; the LDS addresses of a step's row blocks
                     // differ by immediates.  Only the LAST column step of a footprint can hold uncovered columns: it alone selects.
                     constexpr int NRB_MAX = MTILE_H / 8;
-                    int trowB[NRB_MAX];
-                    float wv0[NRB_MAX], wv1[NRB_MAX];
-#pragma unroll
-                    for (int rb = 0; rb < NRB_MAX; ++rb) {
-                        const int j = jlo + 8 * rb + ly;
-                        const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
-                        int ty = nearest_index((dy + q_half) * q_invP, n);
-                        if (QUAD) ty = min(ty, n - 1 - ty);
-                        trowB[rb] = (toff + ty * tstride) * 4;
-                        wv0[rb] = (j <= jhi) ? w0 : 0.0f;
-                        wv1[rb] = (j <= jhi) ? w1 : 0.0f;       // (its own +0: val * w1 with val = 0 would be NaN for a non-finite quantity)
-                    }
                     const int nrb = ((jhi - jlo) >> 3) + 1;                 // row blocks the footprint touches in this tile (wave-uniform)
                     const char *Tb = reinterpret_cast<const char *>(T);
                     char *rowp = reinterpret_cast<char *>(tile) + ((jlo + ly) * MSTR) * 8;      // this lane's pixel row of block 0
                     auto draw = [&](auto nrb_c) {
                         constexpr int NRB = decltype(nrb_c)::value;
+                        // (only the row blocks the footprint touches are prepared: this set-up, not the stepping, was most of the
+                        // kernel's vector instructions -- 7e7 (footprint, tile) pairs at 1e9 particles)
+                        int trowB[NRB];
+                        float wv0[NRB], wv1[NRB];
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb) {
+                            const int j = jlo + 8 * rb + ly;
+                            const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
+                            int ty = nearest_index((dy + q_half) * q_invP, n);
+                            if (QUAD) ty = min(ty, n - 1 - ty);
+                            trowB[rb] = (toff + (ty << tshift)) * 4;
+                            wv0[rb] = (j <= jhi) ? w0 : 0.0f;
+                            wv1[rb] = (j <= jhi) ? w1 : 0.0f;       // (its own +0: val * w1 with val = 0 would be NaN for a non-finite quantity)
+                        }
                         auto step = [&](int ib, auto partial_c) {
                             constexpr bool PARTIAL = decltype(partial_c)::value;
                             const int i = ib + lx;
@@ -895,23 +897,23 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                     // masks combined per step (one scalar AND), the products selected to +0, rows wrapped into the tile instead of
                     // padding it -- measured faster than the form above here (1e7 weighted: 2.00 against 2.34 ms; masked: 2.06)
                     constexpr int NRB_MAX = MTILE_H / 8;
-                    int trowB[NRB_MAX], rowA[NRB_MAX];
-                    bool rowok[NRB_MAX];                                    // (lane masks in scalar registers)
-#pragma unroll
-                    for (int rb = 0; rb < NRB_MAX; ++rb) {
-                        const int j = jlo + 8 * rb + ly;
-                        const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
-                        int ty = nearest_index((dy + q_half) * q_invP, n);
-                        if (QUAD) ty = min(ty, n - 1 - ty);
-                        trowB[rb] = (toff + ty * tstride) * 4;
-                        rowA[rb] = (j & (MTILE_H - 1)) * (MSTR * 8);
-                        rowok[rb] = j <= jhi;
-                    }
                     const int nrb = ((jhi - jlo) >> 3) + 1;                 // row blocks the footprint touches in this tile (wave-uniform)
                     const char *Tb = reinterpret_cast<const char *>(T);
                     char *tileb = reinterpret_cast<char *>(tile);
                     auto draw = [&](auto nrb_c) {
                         constexpr int NRB = decltype(nrb_c)::value;
+                        int trowB[NRB], rowA[NRB];
+                        bool rowok[NRB];                                    // (lane masks in scalar registers)
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb) {
+                            const int j = jlo + 8 * rb + ly;
+                            const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
+                            int ty = nearest_index((dy + q_half) * q_invP, n);
+                            if (QUAD) ty = min(ty, n - 1 - ty);
+                            trowB[rb] = (toff + (ty << tshift)) * 4;
+                            rowA[rb] = (j & (MTILE_H - 1)) * (MSTR * 8);
+                            rowok[rb] = j <= jhi;
+                        }
                         for (int ib = ilo; ib <= ihi; ib += 8) {
                             const int i = ib + lx;
                             const float dx = ((float)(tx0 + i) + 0.5f) - q_pcx;
@@ -953,7 +955,7 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                             const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
                             int ty = nearest_index((dy + q_half) * q_invP, n);
                             if (QUAD) ty = min(ty, n - 1 - ty);
-                            trow[rb] = (j <= jhi) ? toff + ty * tstride : -1;
+                            trow[rb] = (j <= jhi) ? toff + (ty << tshift) : -1;
                         }
                     }
                     for (int ib = ilo; ib <= ihi; ib += 8) {
@@ -1301,6 +1303,8 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     if (hc.n_mid > 0) {
         ta.geom = (const float4 *)ws.mid_geom; ta.w = (const float *)ws.mid_w; ta.n_records = (long long)hc.n_mid;
         ta.split = std::max(1, ctx->mid_split * mth / 32);     // the same number of workgroups per image area for both tile heights
+        // (round 5, 2.5e7 records: 48 / 64 / 96 / 128 / 192 workgroups per tile -> 17.0 / 15.7 / 15.3 / 14.9 / 14.6 ms; 3.3e6 records: flat from 64)
+        if ((long long)hc.n_mid >= 16000000ll && ctx->mid_split == 128) ta.split = ta.split * 3 / 2;
         // a small render block (an interactive frame's first 1e5 particles leave ~3e4 records) does not need 65 536
         // workgroups that each load the LUT: fewer splits in proportion below 2^18 records
         if ((long long)hc.n_mid < (1ll << 18)) ta.split = std::max(4, (int)((long long)ta.split * (long long)hc.n_mid >> 18));
