@@ -556,6 +556,51 @@ def test_gather_kernels_fold_their_accumulators(native, mips):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["weighted", "rgb"])
+def test_huge_records_binned_by_band_or_not(native, mips, mode):
+    """Kernel H2 scans the huge records of its 64-row image band (bins filled by one pass) or, when the bins would not fit the
+    memory budget (option huge_band_mib; 0 = never bin), the whole list: same image, same exact fragment count, against the
+    oracle; R = 300 leaves a partial last band, footprints reach from one band to all of them."""
+    from oracle import oracle_np
+    R, scale, n = 300, 100.0, 6000
+    M, sf = oracle_np.transform_matrix(_rot(0.1, 0.0), np.zeros(3), scale)
+    rs = np.random.RandomState(17)
+    pos = np.zeros((n, 3), dtype=np.float32)
+    pos[:, :2] = rs.uniform(-1.2, 1.2, size=(n, 2)) * scale
+    pos[:, 2] = rs.uniform(-0.5, 0.5, n) * scale
+    P = np.exp(rs.uniform(np.log(64.0), np.log(1500.0), n))
+    P[:40] = [64.0, 64.0001, 127.99, 128.0] * 10          # class boundary and band-edge widths
+    h = (P * scale / (2.0 * R)).astype(np.float32)
+    m = rs.uniform(0.5, 2.0, n).astype(np.float32)
+    q = rs.normal(size=n).astype(np.float32)
+    rgb = rs.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32)
+    ctx = native.Context(R, 4 if mode == "rgb" else 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, None if mode == "rgb" else m)
+    if mode == "rgb":
+        ctx.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
+        want, nfrag = oracle_render(pos, h, rgb[:, 0].copy(), rgb[:, 1].copy(), rgb[:, 2].copy(), 2, M, sf, R, mips)
+        md = native.MODE_RGB
+    else:
+        ctx.upload_quantity(q)
+        want, nfrag = oracle_render(pos, h, m, q, None, 0, M, sf, R, mips)
+        md = native.MODE_WEIGHTED
+    for mib in (6144, 0, 1):                   # binned, never binned, a budget the bins do not fit (6000 records x 5 bands x 24 B < 1 MiB: binned after all)
+        for count in (1, 0):
+            ctx.set_option("huge_band_mib", mib); ctx.set_option("count_fragments", count)
+            ctx.render(M, sf, mode=md)
+            got = ctx.read_image()
+            if mode == "rgb":
+                assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=0), mib
+                assert np.array_equal(got[..., 3], want[..., 3]), mib
+            else:
+                check_2ch(got, want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
+            if count:
+                assert ctx.stats()["n_fragments"] == nfrag, mib
+            assert ctx.stats()["n_huge"] > 4096
+    ctx.close()
+
+
 def test_asymmetric_kernel_lut_uses_full_tables(native, mips):
     """Kernel M keeps only one quadrant of every mip level in LDS when the uploaded LUT is mirror-symmetric bit for bit
     (the reference's radial kernel is); any other LUT must go through the full tables.  Both against the oracle."""
