@@ -42,6 +42,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
             want, nfrag = oracle_c.splat(x, y, z, h, rgb[:, 0].copy(), rgb[:, 1].copy(), rgb[:, 2].copy(), mode=2, M=M, sf=sf, R=R, mips=mips)
         else:
             want, nfrag = oracle_c.splat(x, y, z, h, m, None, None, mode=1, M=M, sf=sf, R=R, mips=mips)
+        if n > 1 and rs.rand() < 0.5:      # the load-time ordering (strata, Morton, blocks by smoothing length): any order must give the same image
+            ctx.reorder_spatial(int(rs.choice([1, 3, 8])), seed)
         # split into two accumulated blocks with several ranges each
         cut = n // 3
         ctx.render(M, sf, np.array([0]), np.array([cut]), clear=True, mode=md)
@@ -57,6 +59,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         continue
     ctx = make_ctx(R, 2)
     ctx.upload_particles(x, y, z, h, m); ctx.upload_quantity(q)
+    if n > 1 and rs.rand() < 0.5:
+        ctx.reorder_spatial(int(rs.choice([1, 3, 8])), seed)
     ctx.set_option("count_fragments", 1)
     ctx.render(M, sf)
     got = ctx.read_image(); nf = ctx.stats()["n_fragments"]
