@@ -472,7 +472,7 @@ int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64
     ctx->stats.n_fragments_stream = (int64_t)hc.n_frag_class[0];
     ctx->stats.n_fragments_mid = (int64_t)hc.n_frag_class[1];
     ctx->stats.n_fragments_huge = (int64_t)hc.n_frag_class[2];
-    ctx->stats.n_fragments_mega = 0;
+    ctx->stats.n_fragments_mega = (int64_t)hc.n_frag_class[3];      // (0 in the product build; the TSP_H2_DEBUG analysis build counts here)
     if (gpu_ms_out) *gpu_ms_out = ms;
     return TSP_OK;
 }
@@ -707,7 +707,12 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         TSP_REQUIRE(value >= 0 && value <= 4096, TSP_EINVAL, "%s out of range", name);
         if (name[0] == 'm') ctx->mid_split = value > 0 ? (int)value : 1;
         else if (name[0] == 'h') ctx->huge_split = (int)value;
-        else ctx->stream_blocks_per_cu = value > 0 ? (int)value : 1;
+        else ctx->stream_blocks_per_cu = (int)value;      // 0 = as many as stay resident
+        return TSP_OK;
+    }
+    if (!strcmp(name, "stream_batch_chunks")) {
+        TSP_REQUIRE(value >= 4 && value <= 4096, TSP_EINVAL, "%s out of range", name);
+        ctx->stream_batch_chunks = (int)value;
         return TSP_OK;
     }
     if (!strcmp(name, "huge_band_mib")) {     // memory the band bins of the huge records may take, MiB (0 = never bin: kernel H2 scans one list)

@@ -31,7 +31,6 @@ namespace tsp {
 //       every covered row:      acc += gy*top ; acc += fy*bot                              -- 2 VALU per pixel
 // against ~14.5 VALU + one 16-byte LDS read per pixel in a per-pixel bilinear gather (the round-1 kernel H).  The sum has the same non-negative terms as the
 // canonical bilinear form in a different association (relative rounding differences of ~1e-7).
-#define TSP_DPP_QUAD(t) "quad_perm:[" #t "," #t "," #t "," #t "] row_mask:0xf bank_mask:0xf"
 
 template <int T> __device__ __forceinline__ void fmac_quad(float &acc, float rowval, float v) {
     static_assert(T >= 0 && T < 4, "quad lane");
@@ -72,7 +71,9 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     float *PT = smem;                                                        // [PT_ROWS][PT_STRIDE]
     float2 *rt_all = reinterpret_cast<float2 *>(smem + ((PT_ROWS * PT_STRIDE + 3) & ~3));   // per wave: (fy, gy) of its HR rows
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // (the wave index as a scalar: the strip's origin and edges then live in scalar registers -- as vector values two of them were
+    // spilled and re-read from scratch for every 64 records, behind the record prefetch they then waited for)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int R = a.cam.R;
     // (blockIdx = tile * split + sp: an XCD-aware order -- the workgroups resident on one XCD walking several tiles per slice of the
     // record list, so that the list crosses the fabric once per tile group -- measured 7-11 % SLOWER at 1e9 particles: round 5)
@@ -124,8 +125,11 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
         n_rec = (unsigned)a.hband_count[band];
     }
     const unsigned n_runs = (n_rec + HDEAL - 1) / HDEAL, usplit = (unsigned)a.split;
+    const unsigned lane_run = (unsigned)(lane / HDEAL) * usplit;       // (loop-invariant: the 32-bit vector multiply runs at quarter rate)
     auto fetch = [&](unsigned run0, float4 &g, float &gw1, float &gw2) {
-        const unsigned ri = ((run0 + lane / HDEAL) * usplit + sp) * HDEAL + (lane & (HDEAL - 1));
+        const unsigned ri = (run0 * usplit + sp + lane_run) * HDEAL + (lane & (HDEAL - 1));
+        // unconditional loads (a slot past the end re-reads the last record and is emptied below): under a branch the
+        // compiler cannot count the loads in flight and waits for this prefetch right after issuing it
         g = make_float4(0.f, 0.f, 0.f, 0.f); gw1 = gw2 = 0.0f;
         if (ri < n_rec) {
             g = geom[ri];
@@ -183,15 +187,16 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             {
                 const float d = pyc_own - pcy;
                 const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                // the canonical float32 texel coordinate (tsp_math.h: the oracle forms it with the same operations -- a value next to
+                // a zero texel is proportional to its fraction, so even one ulp of difference here shows at 1e-5 relative)
                 const float v = (d + half) * invP;
                 const float tv = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, 64.0f, -0.5f), 0.0f, 63.0f);
-                const float f0 = __builtin_floorf(tv);
-                const float fr = (tv - f0) * cv;
-                const int r = (int)f0;
+                const float fr = __builtin_amdgcn_fractf(tv) * cv;      // (tv - floor(tv), exact for 0 <= tv <= 63, in one instruction)
+                const int r = (int)tv;                  // (tv >= 0: the conversion truncates = floor)
                 // texel row of the pixel row above = the value of the lane before (v_mov_b32_dpp wave_shr:1); lane 0 and
                 // row 0 of the second half are excluded by `myrow > 0` below
                 const int rprev = __builtin_amdgcn_mov_dpp(r, 0x138, 0xf, 0xf, false);
-                r512 = r * (PT_STRIDE * 4);
+                r512 = __mul24(r, PT_STRIDE * 4);      // (v_mul_u32_u24: full rate; v_mul_lo_u32 takes four issue slots)
                 asm volatile("" ::: "memory");          // (in-order LDS: the previous footprint's table reads are done)
                 rt[lane] = make_float2(fr, cv - fr);      // (every lane writes: the table has 64 slots per wave, the rows sit in the first HR)
                 asm volatile("" ::: "memory");
@@ -226,16 +231,17 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 const float d = pxc[w] - pcx;
-                const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
+                const bool covered = __builtin_fabsf(d) < half;
                 const float u = (d + half) * invP;
                 const float tu = __builtin_amdgcn_fmed3f(__builtin_fmaf(u, 64.0f, -0.5f), 0.0f, 63.0f);
-                const float f0 = __builtin_floorf(tu);
-                const float fr = (tu - f0) * cv;        // uncovered column: both weights 0
-                caddr[w] = ((int)f0) * 4;
-                // density: the particle weight rides on the column factors, so a pixel costs two FMAs
-                fxs[w] = (NACC == 1) ? fr * wq.x : fr;
-                gxs[w] = (NACC == 1) ? (cv - fr) * wq.x : (cv - fr);
-                if (CNT) ncov_x += (cv != 0.0f);
+                caddr[w] = ((int)tu) * 4;
+                // uncovered column: both weights 0.  Density: the particle weight rides on the column factors, so a pixel costs two FMAs
+                // (fr * (c w) and (1 - fr) * (c w) with c = 0 or 1: the same bits as (fr c) * w and (c - fr c) * w)
+                const float cw = covered ? ((NACC == 1) ? wq.x : 1.0f) : 0.0f;
+                const float fr = __builtin_amdgcn_fractf(tu);
+                fxs[w] = fr * cw;
+                gxs[w] = (1.0f - fr) * cw;
+                if (CNT) ncov_x += covered ? 1 : 0;
             }
             float top[W], bot[W];
             float2 nxt[W];                              // prefetched pair of texel row r + 2
@@ -323,7 +329,9 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             if (CNT && lane == 0) {
                 atomicAdd(&a.cnt->n_frag_class[0], 1ull);
                 atomicAdd(&a.cnt->n_frag_class[1], (unsigned long long)__popcll((unsigned long long)covmask));
-                atomicAdd(&a.cnt->n_frag_class[3], (unsigned long long)__popcll((unsigned long long)chgmask));
+                unsigned long long groups = 0;        // row groups of four with a covered row (each costs 8 FMAs per column register)
+                for (int k = 0; k < NG; ++k) groups += (((unsigned long long)covmask >> (4 * k)) & 15ull) ? 1ull : 0ull;
+                atomicAdd(&a.cnt->n_frag_class[3], (unsigned long long)__popcll((unsigned long long)chgmask) + (groups << 32));
             }
 #endif
         }

@@ -60,7 +60,7 @@ struct Record4 {   // rgb variant (24 B)
 };
 
 struct Counters {      // device-side, zeroed per render call
-    unsigned long long n_small, n_mid, n_huge, n_culled, n_fragments, huge_count, pad0, pad1;
+    unsigned long long n_small, n_mid, n_huge, n_culled, n_fragments, huge_count, next_chunk, pad1;     // next_chunk: kernel S's batch counter
     unsigned long long n_frag_class[4];   // n_fragments by the kernel that drew them: S, M, H2, (unused)
 };
 
@@ -134,7 +134,8 @@ struct tsp_context {
     int huge_variant = 1;             // kernel H2's strip shape / occupancy: 1 = auto (density: 64x32 strips at 8 waves/SIMD from 7e5 records, 64x16 below; two channels 64x16 at 7; rgb at 5), 2 / 4-7 = A/B builds
     int mid_split = 128, huge_split = 0;  // workgroups per image tile of kernels M / H2 (0 = auto)
     int reorder_interleave = 2;     // tsp_reorder_spatial's arrangement inside every 512-particle block: 0 Morton order, 1 transposed 64 x 8, 2 by descending smoothing length (tsp_data.hip)
-    int stream_blocks_per_cu = 100;  // kernel S grid bound: ~10 chunks per workgroup at 1e8 particles balances dense and sparse chunks
+    int stream_blocks_per_cu = 0;    // kernel S: persistent workgroups per CU (0 = what the occupancy query reports)
+    int stream_batch_chunks = 8;     // kernel S: the largest batch of consecutive chunks a workgroup takes from the shared counter
     bool chunk_cull = true;           // chunks (512 consecutive particles) whose bounds lie outside the view are skipped by kernel S
                                       // unread: pays with a load-time spatial order (tsp_reorder_spatial); identical results
     int64_t chunk_culled_particles = 0;   // of the last render call

@@ -49,6 +49,9 @@ __device__ __forceinline__ void gatomic_add(double *addr, double v) {
     __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
+// DPP modifier: every lane reads the operand from lane t of its own quad
+#define TSP_DPP_QUAD(t) "quad_perm:[" #t "," #t "," #t "," #t "] row_mask:0xf bank_mask:0xf"
+
 __device__ __forceinline__ void latomic_add(double *addr, float v) {
     __hip_atomic_fetch_add(addr, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }

@@ -90,8 +90,8 @@ struct StreamArgs {
     const int64_t *ranges;     // starts[n] | lens[n] | chunk_prefix[n+1]
     int n_ranges;
     int n_chunks;
-    int chunks_per_block;
-    int min_chunks_per_block;  // chunk culling: the smallest share of surviving chunks a workgroup takes (see the kernel)
+    int chunks_per_block;      // chunks of a workgroup's first (static) batch = the largest batch it takes from the shared counter
+    int dynamic;               // 1: workgroups are persistent and take further batches from Counters::next_chunk (see the kernel)
     Camera cam;
     const float *mips;
     double *img;
@@ -249,24 +249,31 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
     __shared__ unsigned s_red[SWAVES][2], s_mbb[SWAVES][2];
     __shared__ int s_cnt[SWAVES];
     __shared__ long long s_base[2];
+    __shared__ int s_batch;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int R, c_begin, c_end;
+    // Work distribution.  The list of chunks to draw (all of them, or the survivors of the culling pass, whose number only the device
+    // knows) is cut into BATCHES of consecutive chunks.  Workgroup b starts on batch b; with `dynamic` the launch holds only about as
+    // many workgroups as the device keeps resident, and each takes further batches from a shared counter (Counters::next_chunk)
+    // until the list is exhausted -- chunks differ in cost by an order of magnitude (a chunk of the dense core rasterises a few
+    // hundred pixels, one of the outskirts tens of thousands), and with static shares the last workgroups set the kernel's time:
+    // one shard of the 1e9-particle snapshot took 2.5 ms where its share of the whole snapshot's time is 1.8.  Batches shrink
+    // towards the end of the list (a batch is 1 / (2 gridDim) of what is left, between S_BATCH_MIN chunks and chunks_per_block).
+    // A batch is taken one batch AHEAD (while the first chunk of the current one is drawn), so the attribute prefetch of the
+    // next chunk runs across batch borders.  [b0, b1) = current batch, [n0, n1) = the next one (NO_CHUNK: none / not yet known).
+    constexpr int NO_CHUNK = 0x7fffffff, S_BATCH_MIN = 4;
+    int R, b0, b1, n0 = NO_CHUNK, n1 = NO_CHUNK;
+    auto list_size = [&]() -> int {
+        CArgs *ap = KA();
+        return ap->alive ? (int)ap->cull_info[0] : ap->n_chunks;
+    };
     {
         CArgs *ap = KA();
         R = ap->cam.R;
-        // With chunk culling the launch is sized for ALL chunks and the workgroups share out the survivors, whose number only
-        // the device knows: an even share per workgroup (not the first alive / chunks_per_block workgroups at the unculled
-        // share: a strongly zoomed view would run on a handful of them), but never fewer than min_chunks_per_block consecutive
-        // chunks (window set-up and final flush are paid per workgroup).  A workgroup without a share leaves before it touches LDS.
-        int per = ap->chunks_per_block, n_todo = ap->n_chunks;
-        if (ap->alive) {
-            n_todo = (int)ap->cull_info[0];
-            per = min(per, max(ap->min_chunks_per_block, (n_todo + (int)gridDim.x - 1) / (int)gridDim.x));
-        }
-        c_begin = blockIdx.x * per;
-        c_end = min(c_begin + per, n_todo);
-        if (c_begin >= c_end) return;
+        const int per = ap->chunks_per_block, n_todo = list_size();
+        b0 = blockIdx.x * per;
+        b1 = min(b0 + per, n_todo);
+        if (b0 >= b1) return;                              // a workgroup without a batch leaves before it touches LDS
         const float *mips = ap->mips;
         for (int i = tid; i < WC * WIN * WIN; i += SBLOCK) win[i] = 0.0;
         for (int i = tid; i < T23_FLOATS; i += SBLOCK) {
@@ -358,12 +365,26 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
     int64_t first = 0, first_next = 0;
     int cnt = 0, cnt_next = 0;
     // (the list entry of chunk c + 1 is fetched a chunk early, behind the attribute loads: nothing waits for it)
-    int id_next = 0;
-    if (c_begin < c_end) {
-        locate(chunk_id(c_begin), first, cnt); load_chunk(first, cnt);
-        if (c_begin + 1 < c_end) id_next = chunk_id(c_begin + 1);
-    }
-    for (int c = c_begin; c < c_end; ++c) {
+    int id_next = 0, id_next_of = NO_CHUNK;        // list entry id_next belongs to list position id_next_of
+    // the chunk after list position x, as far as this workgroup knows it now
+    auto successor = [&](int x) -> int {
+        if (x >= b0 && x < b1) return (x + 1 < b1) ? x + 1 : n0;
+        return (x + 1 < n1) ? x + 1 : NO_CHUNK;     // x lies in the next batch: the batch after that is not known yet
+    };
+    locate(chunk_id(b0), first, cnt); load_chunk(first, cnt);
+    if (b0 + 1 < b1) { id_next = chunk_id(b0 + 1); id_next_of = b0 + 1; }
+    bool batch_head = true;                         // c is the first chunk of its batch: the next batch is taken now
+    for (int c = b0;;) {
+        // the size of the batch taken now: a share of what is left of the list (uniform)
+        int grab = 0;
+        if (batch_head) {
+            CArgs *ap = KA();
+            if (ap->dynamic) {
+                const int n_todo = list_size();
+                // (a batch that ends the list: nothing is left to take)
+                if (b1 < n_todo) grab = max(S_BATCH_MIN, min(ap->chunks_per_block, (n_todo - b0) / (2 * (int)gridDim.x)));
+            }
+        }
 
         // ---- phase 1: projection, exact covered pixel ranges, classification ------------------------------------
         // Bounding boxes are kept as PACKED 16-bit pixel pairs (x | y << 16; the image has <= 16384 pixels per side):
@@ -422,9 +443,14 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         }
 
         // the next chunk's attributes start to load now; phases 2 - 5 of this chunk hide their latency
-        if (c + 1 < c_end) {
-            locate(id_next, first_next, cnt_next); load_chunk(first_next, cnt_next);
-            if (c + 2 < c_end) id_next = chunk_id(c + 2);
+        // (a batch holds >= 2 chunks unless it ends the list, and the next batch is known from the first chunk's phase 5 on:
+        // when c is the last chunk of its batch, n0 is final)
+        const int c_next = successor(c);
+        if (c_next != NO_CHUNK) {
+            const int id = (id_next_of == c_next) ? id_next : chunk_id(c_next);
+            locate(id, first_next, cnt_next); load_chunk(first_next, cnt_next);
+            const int c_next2 = successor(c_next);
+            if (c_next2 != NO_CHUNK) { id_next = chunk_id(c_next2); id_next_of = c_next2; }
         }
 
         // ---- phase 2: the chunk's small-footprint bounding box places the LDS window (uniform) ------
@@ -483,9 +509,11 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         // their results are published after phase 4: the round trip to L2 (and the wait for the next chunk's attribute loads
         // queued before it) overlaps the rasteriser instead of holding all four waves at a barrier
         long long r_mid = 0, r_huge = 0;
+        unsigned r_batch = 0;
         if (tid == 0) {
             CArgs *ap = KA();
             Counters *cntp = ap->cnt;
+            if (grab) r_batch = atomicAdd(reinterpret_cast<unsigned *>(&cntp->next_chunk), (unsigned)grab);
             if (mid_total) r_mid = (long long)atomicAdd(&cntp->n_mid, (unsigned long long)mid_total);
             if (huge_total) r_huge = (long long)atomicAdd(&cntp->n_huge, (unsigned long long)huge_total);
             ap->seg_count[c] = mid_total;
@@ -642,9 +670,16 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         // ---- phase 5: append the deferred footprints -----------------------------------------------
         if (tid == 0) {
             s_base[0] = r_mid; s_base[1] = r_huge;
+            if (grab) s_batch = (int)r_batch;
             KA()->seg_offset[c] = r_mid;
         }
         __syncthreads();
+        if (grab) {
+            // the counter counts the chunks handed out beyond the static first batches
+            CArgs *ap = KA();
+            const int n_todo = list_size(), start = (int)gridDim.x * ap->chunks_per_block + s_batch;
+            if (start < n_todo) { n0 = start; n1 = min(start + grab, n_todo); }
+        }
         const long long mid_base = s_base[0], huge_base = s_base[1];
         {
             CArgs *ap = KA();
@@ -672,7 +707,11 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                 }
             }
         }
+        if (c_next == NO_CHUNK) break;
         first = first_next; cnt = cnt_next;
+        batch_head = false;
+        if (c + 1 == b1) { b0 = n0; b1 = n1; n0 = n1 = NO_CHUNK; batch_head = true; }
+        c = c_next;
     }
     __syncthreads();
     flush();
@@ -700,6 +739,9 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
 constexpr int MT = 512;              // threads per workgroup of kernel M (8 waves share tile + LUT)
 #ifndef TSP_M_BRANCHFREE
 #define TSP_M_BRANCHFREE 1
+#endif
+#ifndef TSP_M_QUADROWS
+#define TSP_M_QUADROWS 1
 #endif
 // rows of one channel of kernel M's LDS tile: with the branch-free stepping of a density render a lane up to 7 rows below the
 // tile's last row adds +0 to "its" pixel, so the tile carries 7 rows nobody reads
@@ -829,7 +871,82 @@ __global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
                     const int pk = __builtin_amdgcn_readlane(packed, src);
                     const int ilo = pk & 63, ihi = (pk >> 6) & 63, jlo = (pk >> 12) & 63, jhi = (pk >> 18) & 63, lvl = pk >> 24;
                     const int n = 64 >> lvl, toff = QUAD ? mipq_offset(lvl) : mip_offset(lvl), tshift = QUAD ? 5 - lvl : 6 - lvl;      // LUT row stride = 1 << tshift
-                  if constexpr (TSP_M_BRANCHFREE && MODE != TSP_MODE_RGB && WC == 1) {
+                  if constexpr (TSP_M_QUADROWS && MODE != TSP_MODE_RGB && WC == 1) {
+                    // Branch-free 8 x 8 stepping with the row set-up SHARED across the quad.  A lane (ly, lx) of the 8 x 8 step draws pixel
+                    // rows jlo + 8 rb + ly (rb = 0 .. 3) of the footprint: in the form below every lane worked out the LUT row and the
+                    // weight of each of its <= 4 rows itself -- the same ~14 instructions per row block on all eight lanes of a pixel row,
+                    // and at 1e9 particles 7e7 (footprint, tile) pairs made that most of this kernel's vector instructions.  Here lane
+                    // (ly, lx) evaluates ONE row, that of row block lx & 3: the four lanes of a quad hold the LUT row addresses and
+                    // weights of the four row blocks of their ly, and a row block's value reaches the quad as the DPP operand
+                    // (quad_perm) of the instruction that uses it (the address add, the multiply): no extra instruction, no LDS.
+                    // The same float32 operations on the same operands: bit-identical images.  1e9 particles: 14.35 -> 14.0 ms,
+                    // 1e8: 4.43 -> 4.22.  (Sharing the COLUMN set-up too -- lane l evaluates column ilo + l once per footprint, a
+                    // step fetches the value of lane 8 s + lx with ds_bpermute_b32 -- halved the kernel's vector instructions and
+                    // measured SLOWER, 15.4 ms: the kernel is bound by its LDS pipe, and that put one more operation per step on it.)
+                    constexpr int NRB_MAX = MTILE_H / 8;
+                    static_assert(NRB_MAX <= 4, "a quad carries four row blocks");
+                    const int nrb = ((jhi - jlo) >> 3) + 1;                 // row blocks the footprint touches in this tile (wave-uniform)
+                    typedef const __attribute__((address_space(3))) float LdsF;
+                    const int T_lds = (int)(unsigned)(unsigned long long)(LdsF *)T;      // (an LDS pointer is a 32-bit byte address)
+                    int trow_q; float w_q;
+                    {
+                        const int j = jlo + 8 * (lx & 3) + ly;
+                        const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
+                        int ty = nearest_index((dy + q_half) * q_invP, n);
+                        if (QUAD) ty = min(ty, n - 1 - ty);
+                        trow_q = T_lds + (toff + (ty << tshift)) * 4;          // LDS address of the LUT row
+                        w_q = (j <= jhi) ? w0 : 0.0f;                       // +0 below the footprint's last row (the tile carries 7 rows for those lanes)
+                    }
+                    auto lut_column = [&](int i) -> int {                   // byte offset of pixel column i's texel in a LUT row
+                        const float dx = ((float)(tx0 + i) + 0.5f) - q_pcx;
+                        int tx = nearest_index((dx + q_half) * q_invP, n);
+                        if (QUAD) tx = min(tx, n - 1 - tx);
+                        return tx * 4;
+                    };
+                    // (DPP operands must not have been written by the two preceding VALU instructions: pinned here, then two wait states)
+                    asm volatile("" : "+v"(trow_q), "+v"(w_q));
+                    asm volatile("s_nop 1");
+                    double *dcol0 = tile + (jlo + ly) * MSTR + ilo + lx;      // this lane's pixel of row block 0, step 0
+                    auto draw = [&](auto nrb_c) {
+                        constexpr int NRB = decltype(nrb_c)::value;
+#pragma unroll
+                        for (int s = 0; s < TILE / 8; ++s) {
+                            const int ib = ilo + 8 * s;
+                            if (ib > ihi) break;
+                            const int txs = lut_column(ib + lx);
+                            auto body = [&](auto partial_c) {
+                                constexpr bool PARTIAL = decltype(partial_c)::value;
+                                float kv[NRB];
+#pragma unroll
+                                for (int rb = 0; rb < NRB; ++rb) {
+                                    int o;
+                                    if (rb == 0) asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(0) : "=v"(o) : "v"(trow_q), "v"(txs));
+                                    if (rb == 1) asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(1) : "=v"(o) : "v"(trow_q), "v"(txs));
+                                    if (rb == 2) asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(2) : "=v"(o) : "v"(trow_q), "v"(txs));
+                                    if (rb == 3) asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(3) : "=v"(o) : "v"(trow_q), "v"(txs));
+                                    kv[rb] = *reinterpret_cast<LdsF *>(o);
+                                }
+                                const bool colok = ib + lx <= ihi;
+#pragma unroll
+                                for (int rb = 0; rb < NRB; ++rb) {
+                                    float val;
+                                    if (rb == 0) asm volatile("v_mul_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(0) : "=v"(val) : "v"(w_q), "v"(kv[rb]));
+                                    if (rb == 1) asm volatile("v_mul_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(1) : "=v"(val) : "v"(w_q), "v"(kv[rb]));
+                                    if (rb == 2) asm volatile("v_mul_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(2) : "=v"(val) : "v"(w_q), "v"(kv[rb]));
+                                    if (rb == 3) asm volatile("v_mul_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(3) : "=v"(val) : "v"(w_q), "v"(kv[rb]));
+                                    if (PARTIAL) { val = colok ? val : 0.0f; asm volatile("" : "+v"(val)); }      // (the select acts on the float32 product)
+                                    latomic_add(dcol0 + 8 * s + rb * 8 * MSTR, val);
+                                }
+                            };
+                            // (wave-uniform) only the last step of a footprint can hold uncovered columns
+                            if (ib + 7 <= ihi) body(std::false_type()); else body(std::true_type());
+                        }
+                    };
+                    if (NRB_MAX == 4 && nrb == 4) draw(std::integral_constant<int, NRB_MAX>());
+                    else if (NRB_MAX >= 3 && nrb == 3) draw(std::integral_constant<int, (NRB_MAX >= 3 ? 3 : 1)>());
+                    else if (nrb == 2) draw(std::integral_constant<int, 2>());
+                    else draw(std::integral_constant<int, 1>());
+                  } else if constexpr (TSP_M_BRANCHFREE && MODE != TSP_MODE_RGB && WC == 1) {
                     // Branch-free 8 x 8 stepping (round 5: density 16.7 -> 15.4 -> 15.1 ms at 1e9 particles; rgb -- three atomics per step on
                     // 16-row tiles -- measured slower and keeps the masked form below).  Per 8-row block rb this lane's LUT row (byte
                     // offset) and its WEIGHT are formed once per footprint: the footprint's weight where the lane's pixel row is covered,
@@ -1232,14 +1349,24 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         sa.p = parts;
         sa.alive = cull ? ws.alive_list : nullptr; sa.cull_info = ws.cull_info;
         sa.ranges = ws.range_prefix; sa.n_ranges = n_ranges; sa.n_chunks = n_chunks;
-        const int max_blocks = ctx->cu_count * ctx->stream_blocks_per_cu;
-        // at least 8 consecutive chunks per workgroup (amortises the window set-up and keeps the window following the chunks),
-        // fewer only for a small render block that would otherwise leave most CUs idle (an interactive first block of 1e5
-        // particles is 196 chunks)
+        // Small render blocks (an interactive first block of 1e5 particles is 196 chunks): one static batch per workgroup, as
+        // few chunks as it takes to give every CU two workgroups.  Otherwise the launch holds the workgroups the device keeps
+        // resident (a few more are harmless: they start late and take what is left) and they share out the list dynamically.
         const int min_cpb = std::max(1, std::min(8, n_chunks / (ctx->cu_count * 2)));
-        sa.chunks_per_block = std::max(min_cpb, (n_chunks + max_blocks - 1) / max_blocks);
-        sa.min_chunks_per_block = min_cpb;
-        const int grid_s = (n_chunks + sa.chunks_per_block - 1) / sa.chunks_per_block;
+        int per_cu = ctx->stream_blocks_per_cu;
+        if (per_cu <= 0) {
+            static int occ_of[2] = {0, 0};          // (per MODE: this is a function template) [one-channel window, all channels]
+            int &occ = occ_of[WCr == 1 ? 0 : 1];
+            if (occ <= 0) {
+                const void *fn = (WCr == 1) ? (const void *)splat_stream_kernel<MODE, 1> : (const void *)splat_stream_kernel<MODE, C>;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, SBLOCK, smem_s) != hipSuccess || occ <= 0) { (void)hipGetLastError(); occ = 4; }
+            }
+            per_cu = occ;
+        }
+        const int resident = ctx->cu_count * per_cu;
+        sa.dynamic = (min_cpb >= 8 && n_chunks > resident * 8) ? 1 : 0;
+        sa.chunks_per_block = sa.dynamic ? std::max(4, ctx->stream_batch_chunks) : min_cpb;
+        const int grid_s = sa.dynamic ? resident : (n_chunks + sa.chunks_per_block - 1) / sa.chunks_per_block;
         sa.cam = cam; sa.mips = ctx->mips; sa.img = ctx->image64;
         sa.mid_geom = (float4 *)ws.mid_geom; sa.mid_w = (float *)ws.mid_w; sa.mid_capacity = ws.mid_capacity;
         sa.huge_geom = (float4 *)ws.huge_geom; sa.huge_w = (float *)ws.huge_w; sa.huge_capacity = ws.huge_capacity;
