@@ -619,3 +619,60 @@ def test_asymmetric_kernel_lut_uses_full_tables(native, mips):
         want, _ = oracle_render(pos, h, m, q, None, 0, M, sf, 300, lut)
         check_2ch(ctx.read_image(), want, abs_terms_image(pos, h, m, q, M, sf, 300, lut))
         ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["density", "weighted", "rgb", "depth"])
+def test_mid_footprints_scatter_or_gather(native, mips, mode):
+    """The footprints below 64 px that kernel S defers are drawn by kernel G (register gather over tile bins of the records; option
+    mid_variant 1, the default) or by kernel M (LDS tile scatter; 0): each against the oracle, exact fragment count included,
+    for every work-item size, with more than 512 footprints per wave strip (float32 accumulators folded into the float64 target),
+    R = 300 (partial last tiles) and widths on the class boundaries and on every mip-level threshold."""
+    from oracle import oracle_np
+    R, scale, n = 300, 100.0, 30000
+    M, sf = oracle_np.transform_matrix(_rot(0.15, -0.1), np.zeros(3), scale)
+    rs = np.random.RandomState(23)
+    pos = np.zeros((n, 3), dtype=np.float32)
+    pos[:, :2] = rs.uniform(-1.1, 1.1, size=(n, 2)) * scale
+    pos[:2000, :2] = rs.uniform(-0.1, 0.1, size=(2000, 2)) * scale          # a dense patch: > 512 footprints on one strip
+    pos[:, 2] = rs.uniform(-0.5, 0.5, n) * scale
+    P = np.exp(rs.uniform(np.log(10.0), np.log(63.9), n))
+    P[:48] = [63.999, 32.0, 32.0001, 16.0, 16.0001, 11.3137, 11.32, 15.99] * 6
+    h = (P * scale / (2.0 * R)).astype(np.float32)
+    m = rs.uniform(0.5, 2.0, n).astype(np.float32)
+    q = rs.normal(size=n).astype(np.float32)
+    rgb = rs.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32)
+    ctx = native.Context(R, 4 if mode == "rgb" else 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, None if mode == "rgb" else m)
+    if mode == "rgb":
+        ctx.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
+        want, nfrag = oracle_render(pos, h, rgb[:, 0].copy(), rgb[:, 1].copy(), rgb[:, 2].copy(), 2, M, sf, R, mips)
+        md = native.MODE_RGB
+    elif mode == "depth":
+        want, nfrag = oracle_render(pos, h, m, None, None, 1, M, sf, R, mips)
+        md = native.MODE_DEPTH
+    else:
+        if mode == "weighted":
+            ctx.upload_quantity(q)
+        want, nfrag = oracle_render(pos, h, m, q if mode == "weighted" else None, None, 0, M, sf, R, mips)
+        md = native.MODE_WEIGHTED
+    ctx.set_option("p_small_milli", 0)         # everything below 64 px goes to the mid list
+    for variant, items in ((1, 0), (1, 64), (1, 8192), (0, 0)):
+        for count in (1, 0):
+            ctx.set_option("mid_variant", variant); ctx.set_option("mid_item_records", items); ctx.set_option("count_fragments", count)
+            ctx.render(M, sf, mode=md)
+            got = ctx.read_image()
+            st = ctx.stats()
+            assert st["n_mid"] > 25000 and st["n_small"] == 0
+            if mode == "rgb":
+                assert np.allclose(got[..., :3], want[..., :3], rtol=1e-5, atol=0), (variant, items)
+                assert np.array_equal(got[..., 3], want[..., 3]), (variant, items)
+            elif mode == "weighted":
+                check_2ch(got, want, abs_terms_image(pos, h, m, q, M, sf, R, mips))
+            else:
+                assert np.allclose(got[..., 0], want[..., 0], rtol=1e-5, atol=0), (variant, items)
+                if mode == "depth":
+                    assert np.allclose(got[..., 1], want[..., 1], rtol=1e-5, atol=1e-30), (variant, items)
+            if count:
+                assert st["n_fragments"] == nfrag, (variant, items)
+    ctx.close()

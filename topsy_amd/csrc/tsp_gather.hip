@@ -8,6 +8,7 @@
 // selected by a default rule -- f32 MFMA has no peak advantage over the VALU on gfx950 and H2 issues half the flop; kernel I is
 // exact only to ~1e-6 of a footprint's peak -- so round 5 removed them; HISTORY.md keeps their designs and measurements.)
 #include <algorithm>
+#include <cmath>
 #include <type_traits>
 
 #include "tsp_pipeline.h"
@@ -365,6 +366,198 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// kernel G: the MID footprints (nearest sampling on mips 0-3, < 64 px) as a register gather
+// ---------------------------------------------------------------------------------------------
+// The same wave-owns-a-strip structure as kernel H2, for the nearest-texel rule: a lane owns one pixel COLUMN of a 64 x HR strip, the
+// accumulators of its HR pixels sit in registers.  Per (footprint, strip) pair a wave evaluates the LUT row of every pixel row once (one
+// row per lane, redistributed through a per-wave LDS table so that a quad of lanes carries the four rows of a group) and the LUT column
+// + weight of every pixel column once (one per lane); a covered pixel row then costs
+//       address = row address (DPP operand, quad_perm) + column offset ;  k = LUT[address] (LDS read) ;  acc += k * weight
+// -- two vector instructions and a 4-byte LDS read per 64 pixels, against a multiply, a float64 conversion and a 9-clock ds_add_f64 per
+// 64 pixels (plus their share of the row / column set-up) in the scatter kernel M, whose LDS atomics bound it.
+// Records: the mid list binned by 64-row image band (bin_records), dealt to the `split` workgroups of a tile as in H2.
+constexpr int GCHUNK_MAX = 2048;          // records per work item of kernel G (fewer for short lists: enough items to fill the device)
+constexpr int G_MAX_TILES = 8192;         // tile counters are kept in LDS by the binning passes (larger images: kernel M)
+
+template <int MODE, int NACC, int HR, int OCC, bool QUAD, bool CNT>
+__global__ __launch_bounds__(H2T, OCC) void splat_mid_gather_kernel(TileArgs a) {
+    constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
+    constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
+    constexpr int TW = 2 * 64, TH = 2 * HR;
+    constexpr int NG = HR / 4;
+    static_assert(HR == 16 || HR == 32, "rows per wave strip");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // the mip pyramid, or (QUAD: the kernel image is mirror-symmetric) the top-left quadrant of each level -- 5.4 KB instead of 21.8:
+    // with the whole pyramid seven workgroups fill a CU's LDS, and a workgroup keeps its share until its LAST wave ends (the four
+    // strips of a tile differ in work): on average four waves per SIMD were resident, not seven
+    constexpr int TSIZE = QUAD ? MIPQ_TOTAL : MIP_TOTAL;
+    float *T = smem;
+    int *rt_all = reinterpret_cast<int *>(smem + TSIZE);               // per wave: LDS address of the LUT row of each of its HR pixel rows
+    typedef const __attribute__((address_space(3))) float LdsF;
+    const int T_lds = (int)(unsigned)(unsigned long long)(LdsF *)T;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R = a.cam.R;
+    // this workgroup's work item (the launch is sized for the largest possible number of items)
+    if ((int)blockIdx.x >= a.item_base[a.n_tiles]) return;
+    const int tile_id = a.item_tile[blockIdx.x];
+    const int chunk = (int)blockIdx.x - a.item_base[tile_id];
+    const int tx0 = (tile_id % a.tiles_x) * TW, ty0 = (tile_id / a.tiles_x) * TH;
+    if (QUAD) {
+        for (int i = tid; i < MIPQ_TOTAL; i += H2T) {
+            const int lvl = i < 1024 ? 0 : (i < 1280 ? 1 : (i < 1344 ? 2 : 3));
+            const int hn = 32 >> lvl, k = i - mipq_offset(lvl);
+            T[i] = a.mips[mip_offset(lvl) + (k / hn) * (2 * hn) + (k % hn)];
+        }
+    } else {
+        for (int i = tid; i < MIP_TOTAL; i += H2T) T[i] = a.mips[i];
+    }
+    int *rt = rt_all + wv * 64;
+    const int *rt_quad = rt + (lane & 3);
+    const int sx = tx0 + 64 * (wv & 1), sy = ty0 + HR * (wv >> 1);
+    const float sx0 = (float)sx, sx1 = (float)(sx + 64), sy0 = (float)sy, sy1 = (float)(sy + HR);
+    const float pxc = (sx + lane < R) ? (float)(sx + lane) + 0.5f : __builtin_inff();
+    const int myrow = lane & (HR - 1);
+    const float pyc_own = (sy + myrow < R) ? (float)(sy + myrow) + 0.5f : __builtin_inff();
+
+    constexpr int FOLD_EVERY = TSP_FOLD_EVERY;
+    float acc[HR][NACC];
+#pragma unroll
+    for (int p = 0; p < HR; ++p)
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) acc[p][c] = 0.0f;
+    unsigned long long n_frag = 0;
+    __syncthreads();                                       // the only workgroup barrier
+    if (sx >= R || sy >= R) return;
+
+    const size_t first = (size_t)a.hband_base[tile_id] + (size_t)chunk * a.item_records;
+    const float4 *geom = a.geom + first;
+    const float *wts = a.w + first * NW;
+    const unsigned n_rec = (unsigned)min(a.item_records, a.hband_count[tile_id] - chunk * a.item_records);
+    auto fetch = [&](unsigned b0, float4 &g, float &gw1, float &gw2) {      // records b0 + lane of the item (one per lane)
+        const unsigned ri = b0 + lane;
+        g = make_float4(0.f, 0.f, 0.f, 0.f); gw1 = gw2 = 0.0f;
+        if (ri < n_rec) {
+            g = geom[ri];
+            gw1 = wts[ri * NW];
+            if (NW == 2) gw2 = wts[ri * NW + 1];
+        }
+    };
+    float4 g_next; float gw1_next, gw2_next;
+    fetch(0, g_next, gw1_next, gw2_next);
+    unsigned run0 = 0;                    // first record of the next batch of 64
+    do {
+    int since_fold = 0;
+    for (; run0 < n_rec && since_fold < FOLD_EVERY; run0 += 64) {
+        const float4 g = g_next;
+        const float gw1 = gw1_next, gw2 = gw2_next;
+        fetch(run0 + 64, g_next, gw1_next, gw2_next);
+        const float g_half = 0.5f * g.z;
+        bool hit;
+        {
+            const float sdx = fmaxf(fmaxf(sx0 - g.x, g.x - sx1), 0.0f), sdy = fmaxf(fmaxf(sy0 - g.y, g.y - sy1), 0.0f);
+            hit = g.z > 0.0f && sdx < g_half && sdy < g_half && !(a.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= a.disc_k2 * g.z * g.z);
+        }
+        unsigned long long hits = __ballot(hit);
+        if (hits == 0ull) continue;
+        since_fold += __popcll(hits);
+        const float g_invP = 1.0f / g.z;
+        const int g_lvl = max(level_for(g.z), 0);
+        const float g_w1 = (MODE == TSP_MODE_RGB) ? gw1 : g.w * gw1;
+        while (hits) {
+            const int src = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const float pcx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.x), src));
+            const float pcy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.y), src));
+            const float half = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_half), src));
+            const float invP = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_invP), src));
+            const int lvl = __builtin_amdgcn_readlane(g_lvl, src);
+            float wq[3];
+            wq[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.w), src));
+            wq[1] = (NACC >= 2) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_w1), src)) : 0.0f;
+            wq[2] = (NACC >= 3) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gw2), src)) : 0.0f;
+            const int n = 64 >> lvl, tshift = QUAD ? 5 - lvl : 6 - lvl;
+            const int tbase = T_lds + (QUAD ? mipq_offset(lvl) : mip_offset(lvl)) * 4;
+            // ---- rows: lane j < HR evaluates the LUT row of pixel row j (the canonical nearest-texel rule, tsp_math.h) ----
+            unsigned covmask;
+            {
+                const float d = pyc_own - pcy;
+                int ty = nearest_index((d + half) * invP, n);
+                if (QUAD) ty = min(ty, n - 1 - ty);
+                asm volatile("" ::: "memory");          // (in-order LDS: the previous footprint's table reads are done)
+                rt[lane] = tbase + (ty << (tshift + 2));
+                asm volatile("" ::: "memory");
+                constexpr unsigned long long ROWS = (1ull << HR) - 1ull;
+                covmask = (unsigned)(__builtin_amdgcn_fcmpf(__builtin_fabsf(d), half, 4 /* FCMP_OLT */) & ROWS);
+            }
+            if (covmask == 0) continue;
+            // ---- this lane's column: texel column (byte offset in a LUT row) and weights (+0 where the column is not covered) ----
+            int tx4;
+            float wl[NACC];
+            {
+                const float d = pxc - pcx;
+                const bool covered = __builtin_fabsf(d) < half;
+                int tx = nearest_index((d + half) * invP, n);
+                if (QUAD) tx = min(tx, n - 1 - tx);
+                tx4 = tx * 4;
+#pragma unroll
+                for (int c = 0; c < NACC; ++c) wl[c] = covered ? wq[c] : 0.0f;
+                if (CNT) n_frag += covered ? (unsigned long long)__popc(covmask) : 0ull;
+            }
+            // ---- row walk: groups of four rows; a group's row addresses sit in the quads (lane l: row 4 k + (l & 3)) ----
+            int roq[2];
+            roq[0] = rt_quad[0];
+#define TSP_G_ROW(K, T_)                                                                                        \
+            if ((covmask >> (4 * (K) + (T_))) & 1) {                                                            \
+                _Pragma("unroll") for (int c = 0; c < NACC; ++c) fmac_plain(acc[4 * (K) + (T_)][c], kv[T_], wl[c]); \
+            }
+#define TSP_G_GROUP(K)                                                                                          \
+            if constexpr ((K) < NG) {                                                                           \
+                if constexpr ((K) + 1 < NG) roq[((K) + 1) & 1] = rt_quad[4 * ((K) + 1)];                         \
+                if (((covmask >> (4 * (K))) & 15u) != 0u) {                                                     \
+                    asm volatile("" : "+v"(roq[(K) & 1]));                                                      \
+                    int ad[4]; float kv[4];                                                                     \
+                    asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(0) : "=v"(ad[0]) : "v"(roq[(K) & 1]), "v"(tx4)); \
+                    asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(1) : "=v"(ad[1]) : "v"(roq[(K) & 1]), "v"(tx4)); \
+                    asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(2) : "=v"(ad[2]) : "v"(roq[(K) & 1]), "v"(tx4)); \
+                    asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(3) : "=v"(ad[3]) : "v"(roq[(K) & 1]), "v"(tx4)); \
+                    _Pragma("unroll") for (int t = 0; t < 4; ++t) kv[t] = *reinterpret_cast<LdsF *>(ad[t]);    \
+                    TSP_G_ROW(K, 0) TSP_G_ROW(K, 1) TSP_G_ROW(K, 2) TSP_G_ROW(K, 3)                               \
+                }                                                                                               \
+            }
+            TSP_G_GROUP(0) TSP_G_GROUP(1) TSP_G_GROUP(2) TSP_G_GROUP(3)
+            TSP_G_GROUP(4) TSP_G_GROUP(5) TSP_G_GROUP(6) TSP_G_GROUP(7)
+#undef TSP_G_GROUP
+#undef TSP_G_ROW
+        }
+    }
+    // ---- add this wave's partial strip into the render target ---------------------------------------
+    {
+        int Rl = R;
+        asm volatile("" : "+s"(Rl));
+        double *img = a.img + ((size_t)sy * Rl + (sx + lane)) * C;
+        asm volatile("" : "+v"(img));
+#pragma unroll
+        for (int ty = 0; ty < HR; ++ty) {
+            const int gx = sx + lane, gy = sy + ty;
+            if (gx < Rl && gy < Rl) {
+                double *d = img + ((size_t)ty * Rl) * C;
+#pragma unroll
+                for (int c = 0; c < NACC; ++c) {
+                    if (acc[ty][c] != 0.0f) gatomic_add(d + c, acc[ty][c]);
+                    acc[ty][c] = 0.0f;
+                }
+            }
+        }
+    }
+    } while (run0 < n_rec);
+    if (CNT) {
+        for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
+        if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[1], n_frag); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // band bins of the huge records
 // ---------------------------------------------------------------------------------------------
 // Every tile of kernel H2 used to scan the WHOLE huge list (at 1e9 particles: 128 tiles x 85 MB through eight non-coherent
@@ -377,7 +570,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 template <int NW>
 __global__ __launch_bounds__(256) void huge_band_fill_kernel(const float4 *__restrict__ geom, const float *__restrict__ w, long long n,
                                                              int R, int n_bands, float4 *__restrict__ out_geom, float *__restrict__ out_w,
-                                                             long long stride, int *__restrict__ band_count) {
+                                                             long long stride, int *__restrict__ band_count, const long long *__restrict__ band_base) {
     constexpr int PER = 4;                 // records per thread
     extern __shared__ int s_band[];        // [n_bands] counts, then [n_bands] bases
     int *s_cnt = s_band, *s_base = s_band + n_bands;
@@ -412,7 +605,7 @@ __global__ __launch_bounds__(256) void huge_band_fill_kernel(const float4 *__res
         if (first + k >= n || b0[k] > b1[k]) continue;
         float w0 = w[(first + k) * NW], w1 = (NW == 2) ? w[(first + k) * NW + 1] : 0.0f;
         for (int b = b0[k]; b <= b1[k]; ++b) {
-            const long long slot = (long long)b * stride + s_base[b] + atomicAdd(&s_cnt[b], 1);
+            const long long slot = (band_base ? band_base[b] : (long long)b * stride) + s_base[b] + atomicAdd(&s_cnt[b], 1);
             out_geom[slot] = g[k];
             out_w[slot * NW] = w0;
             if (NW == 2) out_w[slot * NW + 1] = w1;
@@ -423,7 +616,7 @@ __global__ __launch_bounds__(256) void huge_band_fill_kernel(const float4 *__res
 // bins the huge list when that pays and fits the memory budget; sets ta.hband_* (or leaves them null)
 template <int NW>
 static int bin_huge_records(tsp_context *ctx, TileArgs &ta, const float4 *huge_geom, const float *huge_w, long long n_huge) {
-    ta.hband_count = nullptr; ta.hband_stride = 0;
+    ta.hband_count = nullptr; ta.hband_stride = 0; ta.hband_base = nullptr;
     Workspace &ws = ctx->ws;
     const int n_bands = (ctx->R + HBAND_H - 1) / HBAND_H;
     const size_t rec_bytes = sizeof(float4) + NW * sizeof(float);
@@ -447,11 +640,228 @@ static int bin_huge_records(tsp_context *ctx, TileArgs &ta, const float4 *huge_g
     TSP_HIP(hipMemsetAsync(ws.hband_count, 0, 256 * sizeof(int), st));
     const unsigned grid = (unsigned)((n_huge + 1023) / 1024);
     hipLaunchKernelGGL((huge_band_fill_kernel<NW>), dim3(grid), dim3(256), 2 * n_bands * sizeof(int), st, huge_geom, huge_w, n_huge, ctx->R, n_bands,
-                       (float4 *)ws.hband_geom, (float *)ws.hband_w, (long long)ws.hband_stride, ws.hband_count);
+                       (float4 *)ws.hband_geom, (float *)ws.hband_w, (long long)ws.hband_stride, ws.hband_count, (const long long *)nullptr);
     TSP_HIP(hipGetLastError());
     ta.geom = (const float4 *)ws.hband_geom; ta.w = (const float *)ws.hband_w;
     ta.hband_count = ws.hband_count; ta.hband_stride = ws.hband_stride;
     return TSP_OK;
+}
+
+// ---- tile bins of the mid records (kernel G) ----------------------------------------------------------------------
+// Every mid record is copied into the bin of each 128 x TH-pixel tile its square reaches (a footprint below 64 px, one pixel of margin
+// per side: <= 2 tiles across, <= 3 or 4 down; ~2 on average), in three passes -- count, prefix, fill -- so that the bins are exact in
+// size; a workgroup of kernel G then draws one WORK ITEM: item_records consecutive records of one tile's bin.  Items are equal in size and
+// nearly equal in work (every record of a bin reaches the tile), a tile gets as many as its bin needs, and the launch is greedy over
+// ~5e4 of them: binned by image band only, with the same number of workgroups for every tile, the workgroups of the densest
+// tiles ran ten times longer than the rest and set the kernel's time (1e9 particles: 19.9 / 15.4 / 13.3 ms at 128 / 256 / 512
+// workgroups per tile), and every workgroup scanned the whole band's records for the few that reach its tile.
+
+struct TileSpan { int x0, x1, y0, y1; };
+__device__ __forceinline__ TileSpan tile_span(const float4 g, int R, int th, int tiles_x, int tiles_y) {
+    TileSpan s; s.x0 = s.y0 = 1; s.x1 = s.y1 = 0;
+    const float half = 0.5f * g.z, xl = g.x - half - 1.0f, xh = g.x + half + 1.0f, yl = g.y - half - 1.0f, yh = g.y + half + 1.0f;
+    // (non-finite or off-image squares: no tile; kernel S emits only records that cover a pixel)
+    if (xh >= 0.0f && xl < (float)R && yh >= 0.0f && yl < (float)R && xl == xl && xh == xh && yl == yl && yh == yh) {
+        s.x0 = max(0, (int)__builtin_floorf(fmaxf(xl, 0.0f) * (1.0f / 128.0f)));
+        s.x1 = min(tiles_x - 1, (int)__builtin_floorf(fminf(xh, (float)R) * (1.0f / 128.0f)));
+        s.y0 = max(0, (int)__builtin_floorf(fmaxf(yl, 0.0f) / (float)th));
+        s.y1 = min(tiles_y - 1, (int)__builtin_floorf(fminf(yh, (float)R) / (float)th));
+    }
+    return s;
+}
+// pass 1: records per tile
+__global__ __launch_bounds__(256) void tile_count_kernel(const float4 *__restrict__ geom, long long n, int R, int th, int tiles_x, int tiles_y,
+                                                         int *__restrict__ tile_count) {
+    constexpr int PER = 4;
+    extern __shared__ int s_tile[];
+    const int n_tiles = tiles_x * tiles_y;
+    for (int t = threadIdx.x; t < n_tiles; t += 256) s_tile[t] = 0;
+    __syncthreads();
+    const long long first = ((long long)blockIdx.x * 256 + threadIdx.x) * PER;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (first + k >= n) continue;
+        const TileSpan sp = tile_span(geom[first + k], R, th, tiles_x, tiles_y);
+        for (int ty = sp.y0; ty <= sp.y1; ++ty)
+            for (int tx = sp.x0; tx <= sp.x1; ++tx) atomicAdd(&s_tile[ty * tiles_x + tx], 1);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_tiles; t += 256)
+        if (s_tile[t]) atomicAdd(&tile_count[t], s_tile[t]);
+}
+// between the passes (one workgroup): first record of every bin, first work item of every tile, the item -> tile table
+__global__ __launch_bounds__(1024) void tile_prefix_kernel(const int *__restrict__ tile_count, int n_tiles, long long *__restrict__ tile_base,
+                                                           int *__restrict__ item_base, int *__restrict__ item_tile, int item_capacity, int item_records) {
+    __shared__ long long s_rec[1024];
+    __shared__ int s_item[1024];
+    __shared__ long long s_carry_rec;
+    __shared__ int s_carry_item;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_carry_rec = 0; s_carry_item = 0; }
+    __syncthreads();
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int t = base + tid;
+        const int c = t < n_tiles ? tile_count[t] : 0;
+        const int it = (c + item_records - 1) / item_records;
+        s_rec[tid] = c; s_item[tid] = it;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const long long vr = tid >= o ? s_rec[tid - o] : 0;
+            const int vi = tid >= o ? s_item[tid - o] : 0;
+            __syncthreads();
+            s_rec[tid] += vr; s_item[tid] += vi;
+            __syncthreads();
+        }
+        const long long rec0 = s_carry_rec + s_rec[tid] - c;
+        const int item0 = s_carry_item + s_item[tid] - it;
+        if (t < n_tiles) {
+            tile_base[t] = rec0; item_base[t] = item0;
+            for (int i = 0; i < it; ++i)
+                if (item0 + i < item_capacity) item_tile[item0 + i] = t;
+        }
+        __syncthreads();
+        if (tid == 1023) { s_carry_rec += s_rec[1023]; s_carry_item += s_item[1023]; }
+        __syncthreads();
+    }
+    if (tid == 0) { tile_base[n_tiles] = s_carry_rec; item_base[n_tiles] = s_carry_item; }
+}
+// pass 3: the records into their bins (a workgroup reserves its slots per tile with one global atomic)
+template <int NW>
+__global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict__ geom, const float *__restrict__ w, long long n, int R, int th,
+                                                        int tiles_x, int tiles_y, float4 *__restrict__ out_geom, float *__restrict__ out_w,
+                                                        const long long *__restrict__ tile_base, int *__restrict__ tile_cursor) {
+    constexpr int PER = 4;
+    extern __shared__ int s_tile[];        // [n_tiles] counts, then [n_tiles] bases
+    const int n_tiles = tiles_x * tiles_y;
+    int *s_cnt = s_tile, *s_base = s_tile + n_tiles;
+    for (int t = threadIdx.x; t < n_tiles; t += 256) s_cnt[t] = 0;
+    __syncthreads();
+    const long long first = ((long long)blockIdx.x * 256 + threadIdx.x) * PER;
+    float4 g[PER];
+    TileSpan sp[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        sp[k].x0 = sp[k].y0 = 1; sp[k].x1 = sp[k].y1 = 0;
+        if (first + k < n) {
+            g[k] = geom[first + k];
+            sp[k] = tile_span(g[k], R, th, tiles_x, tiles_y);
+            for (int ty = sp[k].y0; ty <= sp[k].y1; ++ty)
+                for (int tx = sp[k].x0; tx <= sp[k].x1; ++tx) atomicAdd(&s_cnt[ty * tiles_x + tx], 1);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_tiles; t += 256) {
+        const int c = s_cnt[t];
+        s_base[t] = c ? atomicAdd(&tile_cursor[t], c) : 0;
+        s_cnt[t] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (first + k >= n || sp[k].y0 > sp[k].y1 || sp[k].x0 > sp[k].x1) continue;
+        const float w0 = w[(first + k) * NW], w1 = (NW == 2) ? w[(first + k) * NW + 1] : 0.0f;
+        for (int ty = sp[k].y0; ty <= sp[k].y1; ++ty)
+            for (int tx = sp[k].x0; tx <= sp[k].x1; ++tx) {
+                const int t = ty * tiles_x + tx;
+                const long long slot = tile_base[t] + s_base[t] + atomicAdd(&s_cnt[t], 1);
+                out_geom[slot] = g[k];
+                out_w[slot * NW] = w0;
+                if (NW == 2) out_w[slot * NW + 1] = w1;
+            }
+    }
+}
+
+// bins the mid list by tile and builds the work items; sets ta.{geom, w, hband_count (records per tile), hband_base, item_*}
+template <int NW>
+static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geom, const float *mid_w, long long n_mid, int th, int *n_items_bound,
+                           hipStream_t st) {
+    Workspace &ws = ctx->ws;
+    const int tiles_x = (ctx->R + 127) / 128, tiles_y = (ctx->R + th - 1) / th, n_tiles = tiles_x * tiles_y;
+    // a footprint below 64 px with one pixel of margin per side spans < 66 px: two 128-px tiles across, three 64-row (four 32-row) down
+    const int max_copies = 2 * (th >= 64 ? 3 : 4);
+    const int64_t need = (int64_t)max_copies * n_mid;
+    if (ws.mband_capacity < need) {
+        if (ws.mband_geom) TSP_HIP(hipFree(ws.mband_geom));
+        if (ws.mband_w) TSP_HIP(hipFree(ws.mband_w));
+        if (ws.mitem_tile) TSP_HIP(hipFree(ws.mitem_tile));
+        ws.mband_geom = ws.mband_w = nullptr; ws.mitem_tile = nullptr;
+        ws.mband_capacity = need + need / 8 + 1024;
+        TSP_HIP(hipMalloc(&ws.mband_geom, (size_t)ws.mband_capacity * sizeof(float4)));
+        TSP_HIP(hipMalloc(&ws.mband_w, (size_t)ws.mband_capacity * 2 * sizeof(float)));
+        TSP_HIP(hipMalloc((void **)&ws.mitem_tile, ((size_t)ws.mband_capacity / 64 + G_MAX_TILES + 1) * sizeof(int)));
+    }
+    if (!ws.mband_count) {
+        TSP_HIP(hipMalloc((void **)&ws.mband_count, 2 * G_MAX_TILES * sizeof(int)));               // counts | fill cursors
+        TSP_HIP(hipMalloc((void **)&ws.mband_base, (G_MAX_TILES + 1) * sizeof(long long)));
+        TSP_HIP(hipMalloc((void **)&ws.mitem_base, (G_MAX_TILES + 1) * sizeof(int)));
+    }
+    // records per item: short items balance a short list over the device, long ones amortise a workgroup's LUT load and final flush.
+    // Measured best (one MI355X, 1024^2): 64 records at 3.4e4 mid records, 256 at 3.5e5, 512 at 3.3e6, 2048 at 2.5e7 (512 / 1024 / 2048 /
+    // 4096 there: 14.2 / 13.0 / 12.4 / 13.3 ms) -- about 0.35 sqrt(n), rounded to a power of two
+    int item_records = ctx->mid_item_records;
+    if (item_records <= 0) {
+        const double want = 0.35 * std::sqrt((double)n_mid);
+        item_records = 64;
+        while (item_records < GCHUNK_MAX && (double)item_records * 1.41 < want) item_records *= 2;
+    }
+    const int item_capacity = (int)std::min<int64_t>(need / item_records + n_tiles, ws.mband_capacity / 64 + G_MAX_TILES);
+    TSP_HIP(hipMemsetAsync(ws.mband_count, 0, 2 * G_MAX_TILES * sizeof(int), st));
+    const unsigned grid = (unsigned)((n_mid + 1023) / 1024);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(grid), dim3(256), n_tiles * sizeof(int), st, mid_geom, n_mid, ctx->R, th, tiles_x, tiles_y, ws.mband_count);
+    hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int *)ws.mband_count, n_tiles, ws.mband_base, ws.mitem_base, ws.mitem_tile, item_capacity, item_records);
+    hipLaunchKernelGGL((tile_fill_kernel<NW>), dim3(grid), dim3(256), 2 * n_tiles * sizeof(int), st, mid_geom, mid_w, n_mid, ctx->R, th, tiles_x, tiles_y,
+                       (float4 *)ws.mband_geom, (float *)ws.mband_w, (const long long *)ws.mband_base, ws.mband_count + G_MAX_TILES);
+    TSP_HIP(hipGetLastError());
+    ta.geom = (const float4 *)ws.mband_geom; ta.w = (const float *)ws.mband_w;
+    ta.hband_count = ws.mband_count; ta.hband_stride = 0; ta.hband_base = ws.mband_base;
+    ta.item_tile = ws.mitem_tile; ta.item_base = ws.mitem_base; ta.n_tiles = n_tiles; ta.item_records = item_records;
+    *n_items_bound = item_capacity;
+    return TSP_OK;
+}
+
+template <int MODE, int NACC, int HR, int OCC>
+static int launch_mid_gather_kernel(tsp_context *ctx, TileArgs ta, const float4 *mid_geom, const float *mid_w, long long n_mid, hipStream_t st) {
+    const bool quad = ctx->lut_mirror_symmetric && !ctx->debug_gather_full_lut;
+    const size_t smem = (size_t)(quad ? MIPQ_TOTAL : MIP_TOTAL) * sizeof(float) + (H2T / 64) * 64 * sizeof(int);
+    int rc, n_items_bound = 0;
+    ta.n_records = n_mid;
+    ta.tiles_x = (ctx->R + 127) / 128;
+    if ((rc = bin_mid_records<(MODE == TSP_MODE_RGB) ? 2 : 1>(ctx, ta, mid_geom, mid_w, n_mid, 2 * HR, &n_items_bound, st))) return rc;
+    const dim3 grid(n_items_bound);
+    if (quad) {
+        if (ta.count_frag) hipLaunchKernelGGL((splat_mid_gather_kernel<MODE, NACC, HR, OCC, true, true>), grid, dim3(H2T), smem, st, ta);
+        else hipLaunchKernelGGL((splat_mid_gather_kernel<MODE, NACC, HR, OCC, true, false>), grid, dim3(H2T), smem, st, ta);
+    } else {
+        if (ta.count_frag) hipLaunchKernelGGL((splat_mid_gather_kernel<MODE, NACC, HR, OCC, false, true>), grid, dim3(H2T), smem, st, ta);
+        else hipLaunchKernelGGL((splat_mid_gather_kernel<MODE, NACC, HR, OCC, false, false>), grid, dim3(H2T), smem, st, ta);
+    }
+    TSP_HIP(hipGetLastError());
+    return TSP_OK;
+}
+
+// kernel G serves images of up to G_MAX_TILES tiles (its binning passes keep one counter per tile in LDS)
+bool mid_gather_fits(int R, int mode, bool second_channel) {
+    const int th = (mode == TSP_MODE_RGB || second_channel || mode == TSP_MODE_DEPTH) ? 32 : 64;
+    return (long long)((R + 127) / 128) * ((R + th - 1) / th) <= G_MAX_TILES;
+}
+
+template <int MODE>
+static int launch_mid_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel, const float4 *mid_geom, const float *mid_w, long long n_mid, hipStream_t st) {
+    TSP_REQUIRE(n_mid < (1ll << 28), TSP_EINVAL, "%lld mid footprints in one render block (kernel G indexes its work items with 32 bits)", n_mid);
+    if (MODE == TSP_MODE_RGB) return launch_mid_gather_kernel<MODE, 3, 16, 5>(ctx, ta, mid_geom, mid_w, n_mid, st);
+    if (second_channel) return launch_mid_gather_kernel<MODE, 2, 16, 7>(ctx, ta, mid_geom, mid_w, n_mid, st);
+    return launch_mid_gather_kernel<MODE, 1, 32, 7>(ctx, ta, mid_geom, mid_w, n_mid, st);
+}
+
+int launch_mid_gather(tsp_context *ctx, TileArgs ta, int mode, bool second_channel, const float4 *mid_geom, const float *mid_w,
+                      long long n_mid, hipStream_t st) {
+    switch (mode) {
+        case TSP_MODE_WEIGHTED: return launch_mid_gather_mode<TSP_MODE_WEIGHTED>(ctx, ta, second_channel, mid_geom, mid_w, n_mid, st);
+        case TSP_MODE_DEPTH: return launch_mid_gather_mode<TSP_MODE_DEPTH>(ctx, ta, true, mid_geom, mid_w, n_mid, st);
+        case TSP_MODE_RGB: return launch_mid_gather_mode<TSP_MODE_RGB>(ctx, ta, true, mid_geom, mid_w, n_mid, st);
+    }
+    set_error("bad mode %d", mode);
+    return TSP_EINVAL;
 }
 
 template <int MODE, int NACC, int W, int HR, int OCC>

@@ -72,6 +72,11 @@ struct Workspace {     // per-context scratch of the three-class pipeline (grown
     void *hband_geom = nullptr, *hband_w = nullptr; // the huge records once more, binned by 64-row image band (n_bands regions of hband_stride records)
     int *hband_count = nullptr;                     // records per band
     int64_t hband_stride = 0; int hband_bands = 0;
+    void *mband_geom = nullptr, *mband_w = nullptr; // the mid records binned by tile for kernel G (exact-size bins)
+    int *mband_count = nullptr;                     // records per tile | fill cursors
+    long long *mband_base = nullptr;                // first record of each tile's bin
+    int64_t mband_capacity = 0;                     // records the bins can hold
+    int *mitem_tile = nullptr, *mitem_base = nullptr; // kernel G work items: item -> tile, tile -> first item
     int *seg_count = nullptr;           // per chunk: number of mid records
     long long *seg_offset = nullptr;    // per chunk: first record of its contiguous run
     float4 *seg_bbox = nullptr;         // per chunk: pixel bbox of its mid footprints (x0, y0, x1, y1)
@@ -135,6 +140,9 @@ struct tsp_context {
     int mid_split = 128, huge_split = 0;  // workgroups per image tile of kernels M / H2 (0 = auto)
     int reorder_interleave = 2;     // tsp_reorder_spatial's arrangement inside every 512-particle block: 0 Morton order, 1 transposed 64 x 8, 2 by descending smoothing length (tsp_data.hip)
     int stream_blocks_per_cu = 0;    // kernel S: persistent workgroups per CU (0 = what the occupancy query reports)
+    int debug_gather_full_lut = 0;   // kernel G: 1 = the whole mip pyramid in LDS even when the kernel image is symmetric (measurement aid)
+    int mid_item_records = 0;        // kernel G: records per work item (0 = by list length; a power of two from 64 to 1024)
+    int mid_variant = 1;             // mid footprints: 0 = kernel M (LDS tile scatter), 1 = kernel G (register gather)
     int stream_batch_chunks = 8;     // kernel S: the largest batch of consecutive chunks a workgroup takes from the shared counter
     bool chunk_cull = true;           // chunks (512 consecutive particles) whose bounds lie outside the view are skipped by kernel S
                                       // unread: pays with a load-time spatial order (tsp_reorder_spatial); identical results

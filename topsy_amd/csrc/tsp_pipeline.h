@@ -49,6 +49,10 @@ __device__ __forceinline__ void gatomic_add(double *addr, double v) {
     __hip_atomic_fetch_add(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
+// top-left quadrants of the four mip levels of a mirror-symmetric kernel image (32^2 + 16^2 + 8^2 + 4^2 floats)
+constexpr int MIPQ_TOTAL = 1024 + 256 + 64 + 16;
+__device__ __forceinline__ int mipq_offset(int lvl) { return lvl == 0 ? 0 : (lvl == 1 ? 1024 : (lvl == 2 ? 1280 : 1344)); }
+
 // DPP modifier: every lane reads the operand from lane t of its own quad
 #define TSP_DPP_QUAD(t) "quad_perm:[" #t "," #t "," #t "," #t "] row_mask:0xf bank_mask:0xf"
 
@@ -78,12 +82,21 @@ struct TileArgs {
     float disc_k2;     // (0.5235)^2 when the LUT is zero outside the inscribed disc (exact corner culling), else 0
     // kernel H2: the huge records binned by image band (huge_band_fill_kernel): band b (rows [b, b + 1) * HBAND_H) holds
     // hband_count[b] records at geom + b * hband_stride (w likewise); nullptr = one list for every tile (geom, n_records)
-    const int *hband_count; long long hband_stride;
+    // (kernel G: exact-size bins, band b starts at record hband_base[b])
+    const int *hband_count; long long hband_stride; const long long *hband_base;
+    // kernel G: the mid records binned by tile (hband_count[t] records from record hband_base[t] on); workgroup i draws work item i =
+    // GCHUNK consecutive records of tile item_tile[i]'s bin (that tile's items start at item_base[tile]; item_base[n_tiles] = their number)
+    int n_tiles; const int *item_tile; const int *item_base; int item_records;      // item_records: records per work item (a power of two)
 };
 
 // Kernel H2 (tsp_gather.hip) for the footprints >= 64 px of one render block (the records kernel S appended to the huge list).
 // Records ctx->ev[10] after the launch (per-kernel time: ev[9] .. ev[10]).
 int launch_gather_kernels(tsp_context *ctx, TileArgs ta, int mode, bool second_channel, const float4 *huge_geom, const float *huge_w,
                           long long n_huge);
+
+// Kernel G (tsp_gather.hip): the MID records of one render block as a register gather (option mid_variant); launched on `st`.
+int launch_mid_gather(tsp_context *ctx, TileArgs ta, int mode, bool second_channel, const float4 *mid_geom, const float *mid_w,
+                      long long n_mid, hipStream_t st);
+bool mid_gather_fits(int R, int mode, bool second_channel);      // (larger images keep kernel M)
 
 }  // namespace tsp

@@ -750,8 +750,7 @@ constexpr int mtile_rows(int mode, int wc) { return mtile_h(wc) + ((TSP_M_BRANCH
 // LUT quadrants: the kernel image is a radial function sampled on a grid symmetric about its centre, so every mip level
 // equals its mirror images bit for bit (checked at upload, tsp_set_kernel_mips).  Kernel M then keeps only the top-left
 // quadrant of each level in LDS -- 5.4 KB instead of 21.8 KB -- where that raises the occupancy (rgb), and folds a texel index once per row / column block: i -> min(i, n - 1 - i).
-constexpr int MIPQ_TOTAL = 1024 + 256 + 64 + 16;
-__device__ __forceinline__ int mipq_offset(int lvl) { return lvl == 0 ? 0 : (lvl == 1 ? 1024 : (lvl == 2 ? 1280 : 1344)); }
+// (MIPQ_TOTAL, mipq_offset: tsp_pipeline.h)
 // (Round 5 re-measured padded table rows -- a row stride of 8 * odd floats, so that the 8 x 8 lanes of a step read 64 distinct
 // banks -- at 1e9 particles: kernel M 16.4 ms with and without.  The 30 % bank conflicts of its LUT reads are not on its critical
 // path; the natural layout stays.)
@@ -1416,6 +1415,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
     ta.band_count = ws.band_count; ta.band_list = ws.band_list; ta.band_cap = ws.band_capacity; ta.band_h = band_h;
     ta.cam = cam; ta.mips = ctx->mips; ta.img = ctx->image64; ta.cnt = ctx->counters; ta.tiles_x = tiles_x;
     ta.count_frag = ctx->count_fragments ? 1 : 0;
+    ta.hband_count = nullptr; ta.hband_stride = 0; ta.hband_base = nullptr; ta.n_tiles = 0; ta.item_tile = nullptr; ta.item_base = nullptr;
     // corner culling is exact for the value channels; the rgb counter channel (which also counts zero-valued
     // fragments) is not touched by kernel H2 at all: add_rect_counts() sums the footprint rectangles instead
     ta.disc_k2 = (ctx->lut_zero_outside_disc && !ctx->count_fragments) ? 0.5235f * 0.5235f : 0.0f;
@@ -1427,7 +1427,9 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         TSP_HIP(hipStreamWaitEvent(st_mid, ctx->ev[8], 0));
     }
     TSP_HIP(hipEventRecord(ctx->ev[4], st_mid));
-    if (hc.n_mid > 0) {
+    if (hc.n_mid > 0 && ctx->mid_variant == 1 && mid_gather_fits(ctx->R, MODE, second_channel)) {
+        if ((rc = launch_mid_gather(ctx, ta, MODE, second_channel, (const float4 *)ws.mid_geom, (const float *)ws.mid_w, (long long)hc.n_mid, st_mid))) return rc;
+    } else if (hc.n_mid > 0) {
         ta.geom = (const float4 *)ws.mid_geom; ta.w = (const float *)ws.mid_w; ta.n_records = (long long)hc.n_mid;
         ta.split = std::max(1, ctx->mid_split * mth / 32);     // the same number of workgroups per image area for both tile heights
         // (round 5, 2.5e7 records: 48 / 64 / 96 / 128 / 192 workgroups per tile -> 17.0 / 15.7 / 15.3 / 14.9 / 14.6 ms; 3.3e6 records: flat from 64)
