@@ -52,7 +52,7 @@ VALU_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32 vector peak (256 CUs 
 FMAS_PER_FRAGMENT = {"stream": 1, "mid": 1, "huge": 2}
 B_ALG = {"density": 20, "weighted": 24, "rgb": 28}     # algorithmic bytes/particle
 KERNELS = ("stream", "mid", "huge")        # tsp_stats names of kernels S, M, H2
-KERNEL_SYMBOL = {"stream": "splat_stream_kernel", "mid": "splat_mid_kernel", "huge": "splat_huge2_kernel"}
+KERNEL_SYMBOL = {"stream": "splat_stream_kernel", "mid": "splat_mid_gather_kernel", "huge": "splat_huge2_kernel"}
 # one ncclReduce of the R^2 x C float32 image onto the root over xGMI (ring: 7 steps of 1/8 of the image per link, ~153 GB/s per
 # link and ~20 us per step): an ESTIMATE -- no multi-GPU box was available to this build -- used only by `projected_speedup_1to8`
 REDUCE_ESTIMATE_MS = 0.3

@@ -46,7 +46,7 @@ def test_profile_entry_picks_the_timed_instantiation():
     assert bench.profile_entry(prof, "splat_huge2_kernel", "weighted")[1] == {"x": 3}
     assert bench.profile_entry(prof, "splat_huge2_kernel", "rgb")[1] == {"x": 4}
     assert bench.profile_entry(prof, "splat_stream_kernel", "weighted")[1] == {"x": 8}
-    assert bench.profile_entry(prof, "splat_mid_kernel", "density") == (None, None)
+    assert bench.profile_entry(prof, "splat_mid_gather_kernel", "density") == (None, None)
     # two candidates that cannot be told apart: no guess
     prof["per_kernel"]["tsp::splat_huge2_kernel<0, 1, 1, 16, 8, false>"] = {"x": 9}
     assert bench.profile_entry(prof, "splat_huge2_kernel", "density") == (None, None)

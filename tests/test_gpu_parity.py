@@ -331,7 +331,7 @@ def test_single_particles_and_ties(native, mips, golden):
 @pytest.mark.parametrize("mode", ["weighted", "rgb", "depth"])
 def test_scattered_small_footprints_leave_the_window(native, mips, mode):
     """Unordered particles with footprints of 0-11 px spread over a 1024^2 image: a 512-particle chunk spans far
-    more than kernel S's 64-px LDS window, so most of them take the MID-list route (kernel M, mip 3); the counter
+    more than kernel S's 64-px LDS window, so most of them take the MID-list route (kernel G, mip 3); the counter
     channel of those rgb footprints comes from the rectangle sum.  Everything must still match the oracle."""
     from oracle import oracle_np
     R = 1024
@@ -451,7 +451,7 @@ def test_randomised_views(native, mips, seed):
 @pytest.mark.parametrize("mode", ["weighted", "depth", "rgb"])
 @pytest.mark.parametrize("R", [200, 1024])
 def test_gather_kernel_class_boundaries(native, mips, mode, R):
-    """Footprints right at the class boundary of the tile-gather kernel -- 64 px (nearest mip 0 -> bilinear: kernel M -> H2; a
+    """Footprints right at the class boundary of the tile-gather kernel -- 64 px (nearest mip 0 -> bilinear: kernel G -> H2; a
     texel row per pixel row, the one case where rounding may skip a texel row) -- and at the widths where rounds 1-4 switched
     kernels (128 / 256 / 384 / 512 / 768 px), at arbitrary sub-pixel centres, partly off-screen, against the oracle: image
     within 1e-5 and the exact fragment count.  R = 200 leaves partial tiles and strips on both axes."""
@@ -549,7 +549,7 @@ def test_gather_kernels_fold_their_accumulators(native, mips):
     ctx.set_option("huge_variant", 1)
     ctx.set_option("count_fragments", 1)
     for split in (8, 24):                      # several workgroups per tile
-        ctx.set_option("huge_split", split); ctx.set_option("mid_split", split)
+        ctx.set_option("huge_split", split)
         ctx.render(M, sf)
         assert np.allclose(ctx.read_image()[..., 0], want[..., 0], rtol=1e-5, atol=0), split
         assert ctx.stats()["n_fragments"] == nfrag, split
@@ -602,7 +602,7 @@ def test_huge_records_binned_by_band_or_not(native, mips, mode):
 
 
 def test_asymmetric_kernel_lut_uses_full_tables(native, mips):
-    """Kernel M keeps only one quadrant of every mip level in LDS when the uploaded LUT is mirror-symmetric bit for bit
+    """Kernel G keeps only one quadrant of every mip level in LDS when the uploaded LUT is mirror-symmetric bit for bit
     (the reference's radial kernel is); any other LUT must go through the full tables.  Both against the oracle."""
     from oracle import oracle_np
     M, sf = oracle_np.transform_matrix(_rot(0.2, -0.4), np.zeros(3), 120.0)
@@ -622,11 +622,11 @@ def test_asymmetric_kernel_lut_uses_full_tables(native, mips):
 
 
 @pytest.mark.parametrize("mode", ["density", "weighted", "rgb", "depth"])
-def test_mid_footprints_scatter_or_gather(native, mips, mode):
-    """The footprints below 64 px that kernel S defers are drawn by kernel G (register gather over tile bins of the records; option
-    mid_variant 1, the default) or by kernel M (LDS tile scatter; 0): each against the oracle, exact fragment count included,
-    for every work-item size, with more than 512 footprints per wave strip (float32 accumulators folded into the float64 target),
-    R = 300 (partial last tiles) and widths on the class boundaries and on every mip-level threshold."""
+def test_mid_footprints_gather(native, mips, mode):
+    """The footprints below 64 px that kernel S defers are drawn by kernel G (register gather over tile bins of the records):
+    against the oracle, exact fragment count included, for every work-item size, with more than 512 footprints per wave strip
+    (float32 accumulators folded into the float64 target), R = 300 (partial last tiles) and widths on the class boundaries and
+    on every mip-level threshold."""
     from oracle import oracle_np
     R, scale, n = 300, 100.0, 30000
     M, sf = oracle_np.transform_matrix(_rot(0.15, -0.1), np.zeros(3), scale)
@@ -657,9 +657,9 @@ def test_mid_footprints_scatter_or_gather(native, mips, mode):
         want, nfrag = oracle_render(pos, h, m, q if mode == "weighted" else None, None, 0, M, sf, R, mips)
         md = native.MODE_WEIGHTED
     ctx.set_option("p_small_milli", 0)         # everything below 64 px goes to the mid list
-    for variant, items in ((1, 0), (1, 64), (1, 8192), (0, 0)):
+    for variant, items in ((1, 0), (1, 64), (1, 8192)):
         for count in (1, 0):
-            ctx.set_option("mid_variant", variant); ctx.set_option("mid_item_records", items); ctx.set_option("count_fragments", count)
+            ctx.set_option("mid_item_records", items); ctx.set_option("count_fragments", count)
             ctx.render(M, sf, mode=md)
             got = ctx.read_image()
             st = ctx.stats()

@@ -171,8 +171,8 @@ void tsp_destroy(tsp_context *ctx) {
     tsp_comm_destroy(ctx);
     free_particles(ctx);
     void *ptrs[] = {ctx->image, ctx->image64, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->lut2d, ctx->scratch,
-                    ctx->ws.mid_geom, ctx->ws.mid_w, ctx->ws.huge_geom, ctx->ws.huge_w, ctx->ws.hband_geom, ctx->ws.hband_w, ctx->ws.hband_count, ctx->ws.mband_geom, ctx->ws.mband_w, ctx->ws.mband_count, ctx->ws.mband_base, ctx->ws.mitem_tile, ctx->ws.mitem_base, ctx->ws.seg_count, ctx->ws.seg_offset,
-                    ctx->ws.seg_bbox, ctx->ws.band_count, ctx->ws.band_list, ctx->ws.block_bounds, ctx->ws.alive_list, ctx->ws.cull_info, ctx->ws.range_prefix, ctx->ws.count_diff, ctx->ws.count_band, ctx->sort_keys, ctx->sort_keys_alt, ctx->sort_tmp};
+                    ctx->ws.mid_geom, ctx->ws.mid_w, ctx->ws.huge_geom, ctx->ws.huge_w, ctx->ws.hband_geom, ctx->ws.hband_w, ctx->ws.hband_count, ctx->ws.mband_geom, ctx->ws.mband_w, ctx->ws.mband_count, ctx->ws.mband_base, ctx->ws.mitem_tile, ctx->ws.mitem_base, 
+                    ctx->ws.block_bounds, ctx->ws.alive_list, ctx->ws.cull_info, ctx->ws.range_prefix, ctx->ws.count_diff, ctx->ws.count_band, ctx->sort_keys, ctx->sort_keys_alt, ctx->sort_tmp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (auto &e : ctx->ev)
@@ -698,15 +698,9 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         ctx->debug_no_raster = value != 0;
         return TSP_OK;
     }
-    if (!strcmp(name, "debug_extra_lds")) {
-        TSP_REQUIRE(value >= 0 && value <= 65536, TSP_EINVAL, "%s out of range", name);
-        ctx->debug_extra_lds = (int)value;
-        return TSP_OK;
-    }
-    if (!strcmp(name, "mid_split") || !strcmp(name, "huge_split") || !strcmp(name, "stream_blocks_per_cu")) {
+    if (!strcmp(name, "huge_split") || !strcmp(name, "stream_blocks_per_cu")) {
         TSP_REQUIRE(value >= 0 && value <= 4096, TSP_EINVAL, "%s out of range", name);
-        if (name[0] == 'm') ctx->mid_split = value > 0 ? (int)value : 1;
-        else if (name[0] == 'h') ctx->huge_split = (int)value;
+        if (name[0] == 'h') ctx->huge_split = (int)value;
         else ctx->stream_blocks_per_cu = (int)value;      // 0 = as many as stay resident
         return TSP_OK;
     }
@@ -714,11 +708,6 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
     if (!strcmp(name, "mid_item_records")) {
         TSP_REQUIRE(value == 0 || (value >= 64 && value <= 8192 && (value & (value - 1)) == 0), TSP_EINVAL, "%s: 0 or a power of two from 64 to 8192", name);
         ctx->mid_item_records = (int)value;
-        return TSP_OK;
-    }
-    if (!strcmp(name, "mid_variant")) {      // 0 = kernel M (LDS tile scatter), 1 = kernel G (register gather)
-        TSP_REQUIRE(value == 0 || value == 1, TSP_EINVAL, "%s out of range", name);
-        ctx->mid_variant = (int)value;
         return TSP_OK;
     }
     if (!strcmp(name, "stream_batch_chunks")) {

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 // 64 pixels (plus their share of the row / column set-up) in the scatter kernel M, whose LDS atomics bound it.
 // Records: the mid list binned by 64-row image band (bin_records), dealt to the `split` workgroups of a tile as in H2.
 constexpr int GCHUNK_MAX = 2048;          // records per work item of kernel G (fewer for short lists: enough items to fill the device)
-constexpr int G_MAX_TILES = 8192;         // tile counters are kept in LDS by the binning passes (larger images: kernel M)
+constexpr int G_LDS_TILES = 8192;         // the binning passes keep their tile counters in LDS up to this many tiles (global atomics beyond)
 
 template <int MODE, int NACC, int HR, int OCC, bool QUAD, bool CNT>
 __global__ __launch_bounds__(H2T, OCC) void splat_mid_gather_kernel(TileArgs a) {
@@ -669,25 +669,31 @@ __device__ __forceinline__ TileSpan tile_span(const float4 g, int R, int th, int
     }
     return s;
 }
-// pass 1: records per tile
+// pass 1: records per tile (counted in LDS first when the image has few enough tiles: one global atomic per workgroup and tile)
 __global__ __launch_bounds__(256) void tile_count_kernel(const float4 *__restrict__ geom, long long n, int R, int th, int tiles_x, int tiles_y,
                                                          int *__restrict__ tile_count) {
     constexpr int PER = 4;
     extern __shared__ int s_tile[];
     const int n_tiles = tiles_x * tiles_y;
-    for (int t = threadIdx.x; t < n_tiles; t += 256) s_tile[t] = 0;
-    __syncthreads();
+    const bool lds = n_tiles <= G_LDS_TILES;
+    if (lds) {
+        for (int t = threadIdx.x; t < n_tiles; t += 256) s_tile[t] = 0;
+        __syncthreads();
+    }
+    int *cnt = lds ? s_tile : tile_count;
     const long long first = ((long long)blockIdx.x * 256 + threadIdx.x) * PER;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         if (first + k >= n) continue;
         const TileSpan sp = tile_span(geom[first + k], R, th, tiles_x, tiles_y);
         for (int ty = sp.y0; ty <= sp.y1; ++ty)
-            for (int tx = sp.x0; tx <= sp.x1; ++tx) atomicAdd(&s_tile[ty * tiles_x + tx], 1);
+            for (int tx = sp.x0; tx <= sp.x1; ++tx) atomicAdd(&cnt[ty * tiles_x + tx], 1);
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < n_tiles; t += 256)
-        if (s_tile[t]) atomicAdd(&tile_count[t], s_tile[t]);
+    if (lds) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < n_tiles; t += 256)
+            if (s_tile[t]) atomicAdd(&tile_count[t], s_tile[t]);
+    }
 }
 // between the passes (one workgroup): first record of every bin, first work item of every tile, the item -> tile table
 __global__ __launch_bounds__(1024) void tile_prefix_kernel(const int *__restrict__ tile_count, int n_tiles, long long *__restrict__ tile_base,
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(1024) void tile_prefix_kernel(const int *__restrict
     }
     if (tid == 0) { tile_base[n_tiles] = s_carry_rec; item_base[n_tiles] = s_carry_item; }
 }
-// pass 3: the records into their bins (a workgroup reserves its slots per tile with one global atomic)
+// pass 3: the records into their bins (with LDS counters a workgroup reserves its slots per tile with one global atomic)
 template <int NW>
 __global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict__ geom, const float *__restrict__ w, long long n, int R, int th,
                                                         int tiles_x, int tiles_y, float4 *__restrict__ out_geom, float *__restrict__ out_w,
@@ -733,9 +739,12 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict
     constexpr int PER = 4;
     extern __shared__ int s_tile[];        // [n_tiles] counts, then [n_tiles] bases
     const int n_tiles = tiles_x * tiles_y;
+    const bool lds = n_tiles <= G_LDS_TILES;
     int *s_cnt = s_tile, *s_base = s_tile + n_tiles;
-    for (int t = threadIdx.x; t < n_tiles; t += 256) s_cnt[t] = 0;
-    __syncthreads();
+    if (lds) {
+        for (int t = threadIdx.x; t < n_tiles; t += 256) s_cnt[t] = 0;
+        __syncthreads();
+    }
     const long long first = ((long long)blockIdx.x * 256 + threadIdx.x) * PER;
     float4 g[PER];
     TileSpan sp[PER];
@@ -745,17 +754,20 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict
         if (first + k < n) {
             g[k] = geom[first + k];
             sp[k] = tile_span(g[k], R, th, tiles_x, tiles_y);
-            for (int ty = sp[k].y0; ty <= sp[k].y1; ++ty)
-                for (int tx = sp[k].x0; tx <= sp[k].x1; ++tx) atomicAdd(&s_cnt[ty * tiles_x + tx], 1);
+            if (lds)
+                for (int ty = sp[k].y0; ty <= sp[k].y1; ++ty)
+                    for (int tx = sp[k].x0; tx <= sp[k].x1; ++tx) atomicAdd(&s_cnt[ty * tiles_x + tx], 1);
         }
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < n_tiles; t += 256) {
-        const int c = s_cnt[t];
-        s_base[t] = c ? atomicAdd(&tile_cursor[t], c) : 0;
-        s_cnt[t] = 0;
+    if (lds) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < n_tiles; t += 256) {
+            const int c = s_cnt[t];
+            s_base[t] = c ? atomicAdd(&tile_cursor[t], c) : 0;
+            s_cnt[t] = 0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         if (first + k >= n || sp[k].y0 > sp[k].y1 || sp[k].x0 > sp[k].x1) continue;
@@ -763,7 +775,7 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict
         for (int ty = sp[k].y0; ty <= sp[k].y1; ++ty)
             for (int tx = sp[k].x0; tx <= sp[k].x1; ++tx) {
                 const int t = ty * tiles_x + tx;
-                const long long slot = tile_base[t] + s_base[t] + atomicAdd(&s_cnt[t], 1);
+                const long long slot = tile_base[t] + (lds ? s_base[t] + atomicAdd(&s_cnt[t], 1) : atomicAdd(&tile_cursor[t], 1));
                 out_geom[slot] = g[k];
                 out_w[slot * NW] = w0;
                 if (NW == 2) out_w[slot * NW + 1] = w1;
@@ -780,20 +792,19 @@ static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geo
     // a footprint below 64 px with one pixel of margin per side spans < 66 px: two 128-px tiles across, three 64-row (four 32-row) down
     const int max_copies = 2 * (th >= 64 ? 3 : 4);
     const int64_t need = (int64_t)max_copies * n_mid;
-    if (ws.mband_capacity < need) {
-        if (ws.mband_geom) TSP_HIP(hipFree(ws.mband_geom));
-        if (ws.mband_w) TSP_HIP(hipFree(ws.mband_w));
-        if (ws.mitem_tile) TSP_HIP(hipFree(ws.mitem_tile));
-        ws.mband_geom = ws.mband_w = nullptr; ws.mitem_tile = nullptr;
-        ws.mband_capacity = need + need / 8 + 1024;
+    if (ws.mband_capacity < need || ws.mtile_capacity < n_tiles) {
+        void *olds[] = {ws.mband_geom, ws.mband_w, ws.mitem_tile, ws.mband_count, ws.mband_base, ws.mitem_base};
+        for (void *q : olds)
+            if (q) TSP_HIP(hipFree(q));
+        ws.mband_geom = ws.mband_w = nullptr; ws.mitem_tile = ws.mitem_base = ws.mband_count = nullptr; ws.mband_base = nullptr;
+        ws.mband_capacity = std::max<int64_t>(ws.mband_capacity, need + need / 8 + 1024);
+        ws.mtile_capacity = std::max(ws.mtile_capacity, n_tiles);
         TSP_HIP(hipMalloc(&ws.mband_geom, (size_t)ws.mband_capacity * sizeof(float4)));
         TSP_HIP(hipMalloc(&ws.mband_w, (size_t)ws.mband_capacity * 2 * sizeof(float)));
-        TSP_HIP(hipMalloc((void **)&ws.mitem_tile, ((size_t)ws.mband_capacity / 64 + G_MAX_TILES + 1) * sizeof(int)));
-    }
-    if (!ws.mband_count) {
-        TSP_HIP(hipMalloc((void **)&ws.mband_count, 2 * G_MAX_TILES * sizeof(int)));               // counts | fill cursors
-        TSP_HIP(hipMalloc((void **)&ws.mband_base, (G_MAX_TILES + 1) * sizeof(long long)));
-        TSP_HIP(hipMalloc((void **)&ws.mitem_base, (G_MAX_TILES + 1) * sizeof(int)));
+        TSP_HIP(hipMalloc((void **)&ws.mitem_tile, ((size_t)ws.mband_capacity / 64 + ws.mtile_capacity + 1) * sizeof(int)));
+        TSP_HIP(hipMalloc((void **)&ws.mband_count, 2 * (size_t)ws.mtile_capacity * sizeof(int)));               // counts | fill cursors
+        TSP_HIP(hipMalloc((void **)&ws.mband_base, ((size_t)ws.mtile_capacity + 1) * sizeof(long long)));
+        TSP_HIP(hipMalloc((void **)&ws.mitem_base, ((size_t)ws.mtile_capacity + 1) * sizeof(int)));
     }
     // records per item: short items balance a short list over the device, long ones amortise a workgroup's LUT load and final flush.
     // Measured best (one MI355X, 1024^2): 64 records at 3.4e4 mid records, 256 at 3.5e5, 512 at 3.3e6, 2048 at 2.5e7 (512 / 1024 / 2048 /
@@ -804,13 +815,14 @@ static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geo
         item_records = 64;
         while (item_records < GCHUNK_MAX && (double)item_records * 1.41 < want) item_records *= 2;
     }
-    const int item_capacity = (int)std::min<int64_t>(need / item_records + n_tiles, ws.mband_capacity / 64 + G_MAX_TILES);
-    TSP_HIP(hipMemsetAsync(ws.mband_count, 0, 2 * G_MAX_TILES * sizeof(int), st));
+    const int item_capacity = (int)std::min<int64_t>(need / item_records + n_tiles, ws.mband_capacity / 64 + ws.mtile_capacity);
+    TSP_HIP(hipMemsetAsync(ws.mband_count, 0, 2 * (size_t)ws.mtile_capacity * sizeof(int), st));
+    const bool lds = n_tiles <= G_LDS_TILES;
     const unsigned grid = (unsigned)((n_mid + 1023) / 1024);
-    hipLaunchKernelGGL(tile_count_kernel, dim3(grid), dim3(256), n_tiles * sizeof(int), st, mid_geom, n_mid, ctx->R, th, tiles_x, tiles_y, ws.mband_count);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(grid), dim3(256), lds ? n_tiles * sizeof(int) : 0, st, mid_geom, n_mid, ctx->R, th, tiles_x, tiles_y, ws.mband_count);
     hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int *)ws.mband_count, n_tiles, ws.mband_base, ws.mitem_base, ws.mitem_tile, item_capacity, item_records);
-    hipLaunchKernelGGL((tile_fill_kernel<NW>), dim3(grid), dim3(256), 2 * n_tiles * sizeof(int), st, mid_geom, mid_w, n_mid, ctx->R, th, tiles_x, tiles_y,
-                       (float4 *)ws.mband_geom, (float *)ws.mband_w, (const long long *)ws.mband_base, ws.mband_count + G_MAX_TILES);
+    hipLaunchKernelGGL((tile_fill_kernel<NW>), dim3(grid), dim3(256), lds ? 2 * n_tiles * sizeof(int) : 0, st, mid_geom, mid_w, n_mid, ctx->R, th, tiles_x, tiles_y,
+                       (float4 *)ws.mband_geom, (float *)ws.mband_w, (const long long *)ws.mband_base, ws.mband_count + ws.mtile_capacity);
     TSP_HIP(hipGetLastError());
     ta.geom = (const float4 *)ws.mband_geom; ta.w = (const float *)ws.mband_w;
     ta.hband_count = ws.mband_count; ta.hband_stride = 0; ta.hband_base = ws.mband_base;
@@ -837,12 +849,6 @@ static int launch_mid_gather_kernel(tsp_context *ctx, TileArgs ta, const float4 
     }
     TSP_HIP(hipGetLastError());
     return TSP_OK;
-}
-
-// kernel G serves images of up to G_MAX_TILES tiles (its binning passes keep one counter per tile in LDS)
-bool mid_gather_fits(int R, int mode, bool second_channel) {
-    const int th = (mode == TSP_MODE_RGB || second_channel || mode == TSP_MODE_DEPTH) ? 32 : 64;
-    return (long long)((R + 127) / 128) * ((R + th - 1) / th) <= G_MAX_TILES;
 }
 
 template <int MODE>

@@ -76,14 +76,9 @@ struct Workspace {     // per-context scratch of the three-class pipeline (grown
     int *mband_count = nullptr;                     // records per tile | fill cursors
     long long *mband_base = nullptr;                // first record of each tile's bin
     int64_t mband_capacity = 0;                     // records the bins can hold
+    int mtile_capacity = 0;                         // tiles the per-tile arrays can hold
     int *mitem_tile = nullptr, *mitem_base = nullptr; // kernel G work items: item -> tile, tile -> first item
-    int *seg_count = nullptr;           // per chunk: number of mid records
-    long long *seg_offset = nullptr;    // per chunk: first record of its contiguous run
-    float4 *seg_bbox = nullptr;         // per chunk: pixel bbox of its mid footprints (x0, y0, x1, y1)
-    int64_t seg_capacity = 0;
-    int *band_count = nullptr;          // per image band (<= 32 bands of whole tile rows): chunks whose mid footprints reach it
-    int64_t band_capacity = 0;          // slots per band
-    int *band_list = nullptr;           // [32][seg_capacity] chunk indices, appended by kernel S in arrival order
+    int64_t chunk_capacity = 0;         // chunks alive_list can hold
     float4 *block_bounds = nullptr;     // chunk culling: bounds of every BOUNDS_BLOCK particles (valid while bounds_valid)
     int64_t bounds_capacity = 0;        // blocks
     bool bounds_valid = false;          // cleared whenever positions / smoothing lengths change (upload, generate, reorder)
@@ -102,7 +97,7 @@ struct tsp_context {
     int R = 0, C = 0, Ccap = 0;       // C = active channels (2 or 4) <= Ccap
     bool use_quantity = true;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;    // option overlap_mid_huge: kernel M runs here, concurrently with kernel H2 on `stream`
+    hipStream_t stream2 = nullptr;    // option overlap_mid_huge: kernel G runs here, concurrently with kernel H2 on `stream`
     hipEvent_t ev[12] = {};
     float *image = nullptr;           // R*R*C float32 render target (what read-back, colormap and reduce see)
     double *image64 = nullptr;        // float64 master copy every kernel accumulates into (rounded once per render)
@@ -130,26 +125,23 @@ struct tsp_context {
     int cell_bits = 0;                     // the cells form a (2^cell_bits)^3 grid over the bounding box
     float cell_lo[3] = {0, 0, 0}, cell_width[3] = {0, 0, 0};
     std::vector<int64_t> strata_offsets;   // first index of every stratum of the last reorder_spatial, then n
-    int mid_attr_extra[3] = {-1, -1, -1};   // per render mode: the debug_extra_lds value kernel M's dynamic-LDS limit was last set for
     uint32_t kernel_attr_done = 0;   // bit per kernel family whose dynamic-LDS limit was raised on this context's device
     bool count_fragments = false;
     // pipeline tuning (tsp_set_option)
     float p_small = 16.0f;             // footprints narrower than this many pixels are splatted by kernel S (mips 3 and 2; <= 16: its texel columns are packed 16 x 4 bits)
     int64_t huge_band_budget = 6ll << 30;   // bytes the band bins of the huge records may take (n_bands x n_huge records); above it kernel H2 scans one list
     int huge_variant = 1;             // kernel H2's strip shape / occupancy: 1 = auto (density: 64x32 strips at 8 waves/SIMD from 7e5 records, 64x16 below; two channels 64x16 at 7; rgb at 5), 2 / 4-7 = A/B builds
-    int mid_split = 128, huge_split = 0;  // workgroups per image tile of kernels M / H2 (0 = auto)
+    int huge_split = 0;              // workgroups per image tile of kernel H2 (0 = auto)
     int reorder_interleave = 2;     // tsp_reorder_spatial's arrangement inside every 512-particle block: 0 Morton order, 1 transposed 64 x 8, 2 by descending smoothing length (tsp_data.hip)
     int stream_blocks_per_cu = 0;    // kernel S: persistent workgroups per CU (0 = what the occupancy query reports)
     int debug_gather_full_lut = 0;   // kernel G: 1 = the whole mip pyramid in LDS even when the kernel image is symmetric (measurement aid)
     int mid_item_records = 0;        // kernel G: records per work item (0 = by list length; a power of two from 64 to 1024)
-    int mid_variant = 1;             // mid footprints: 0 = kernel M (LDS tile scatter), 1 = kernel G (register gather)
     int stream_batch_chunks = 8;     // kernel S: the largest batch of consecutive chunks a workgroup takes from the shared counter
     bool chunk_cull = true;           // chunks (512 consecutive particles) whose bounds lie outside the view are skipped by kernel S
                                       // unread: pays with a load-time spatial order (tsp_reorder_spatial); identical results
     int64_t chunk_culled_particles = 0;   // of the last render call
     bool overlap_mid_huge = false;    // option: kernels M and H on two streams (measured: no gain at 1.25e8, +6 % at 1e7)
     bool debug_no_raster = false;    // measurement aid: kernel S classifies and emits records but rasterises nothing (the image is then incomplete)
-    int debug_extra_lds = 0;         // measurement aid: extra dynamic LDS per workgroup of kernel M (lowers its occupancy)
     int cu_count = 256;
     // RCCL
     void *comm = nullptr;

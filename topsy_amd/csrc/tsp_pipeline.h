@@ -16,11 +16,6 @@ constexpr int SBLOCK = TSP_S_BLOCK;  // threads per workgroup of kernel S
 constexpr int SWAVES = SBLOCK / 64;
 constexpr int KPT = TSP_S_KPT;       // particles per thread per chunk
 constexpr int CHUNK = SBLOCK * KPT;  // particles per chunk
-constexpr int TILE = 64;             // tile width of kernel M
-// tile height of kernel M by the number of channels in its LDS tile: 64 x 32 pixels for a density render; 64 x 16 with
-// two or three channels, so that two (rgb) or three workgroups still fit a CU's LDS (rgb: M 31.9 -> 21.0 ms)
-constexpr int mtile_h(int wc) { return wc == 1 ? 32 : 16; }
-constexpr int MSTR = 72;             // LDS row stride (doubles) of the mid tile
 // LDS accumulators are DOUBLE: on gfx950 a conflict-free ds_add_f64 costs ~9 clk per wave-instruction
 // (~11 clk more per extra lane on the same address) while ds_add_f32 costs ~190 (measured,
 // tools/ubench/lds_partial.hip, lds_atomics.hip), and the sums gain precision.
@@ -36,7 +31,6 @@ constexpr int MSTR = 72;             // LDS row stride (doubles) of the mid tile
 template <int WC> struct WinSize { static constexpr int value = (WC == 1) ? TSP_WIN1 : (WC == 2 ? TSP_WIN2 : TSP_WIN4); };
 
 constexpr int HBAND_H = 64;          // image rows per band of the huge-record bins (kernel H2's tallest tile)
-constexpr int NBANDS = 32;           // image bands of the chunk lists kernel S bins for kernel M (each a whole number of 32-row tile rows)
 
 enum { CLS_NONE = 0, CLS_SMALL = 1, CLS_MID = 2, CLS_HUGE = 3 };
 
@@ -71,8 +65,6 @@ constexpr int HDEAL = TSP_HDEAL;            // records per dealing run of the ti
 struct TileArgs {
     const float4 *geom; const float *w;
     long long n_records;
-    const int *seg_count; const long long *seg_offset; const float4 *seg_bbox; int n_chunks;
-    const int *band_count; const int *band_list; long long band_cap; int band_h;   // kernel M: the chunks to look at, per image band
     Camera cam;
     const float *mips;
     double *img;
@@ -94,9 +86,8 @@ struct TileArgs {
 int launch_gather_kernels(tsp_context *ctx, TileArgs ta, int mode, bool second_channel, const float4 *huge_geom, const float *huge_w,
                           long long n_huge);
 
-// Kernel G (tsp_gather.hip): the MID records of one render block as a register gather (option mid_variant); launched on `st`.
+// Kernel G (tsp_gather.hip): the MID records of one render block as a register gather; launched on `st`.
 int launch_mid_gather(tsp_context *ctx, TileArgs ta, int mode, bool second_channel, const float4 *mid_geom, const float *mid_w,
                       long long n_mid, hipStream_t st);
-bool mid_gather_fits(int R, int mode, bool second_channel);      // (larger images keep kernel M)
 
 }  // namespace tsp

@@ -97,8 +97,6 @@ struct StreamArgs {
     double *img;
     float4 *mid_geom;  float *mid_w;   int64_t mid_capacity;
     float4 *huge_geom; float *huge_w;  int64_t huge_capacity;
-    int *seg_count; long long *seg_offset; float4 *seg_bbox;
-    int *band_count; int *band_list; long long band_cap; int band_h;     // per image band: the chunks that have mid footprints there
     Counters *cnt;
     float p_small;
     int count_frag;
@@ -246,7 +244,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
     // lane reads for a pixel its footprint does not cover (phase 4)
     float *T23 = reinterpret_cast<float *>(win + WC * WIN * WIN);
     constexpr int T23_L3 = 17 * 17;
-    __shared__ unsigned s_red[SWAVES][2], s_mbb[SWAVES][2];
+    __shared__ unsigned s_red[SWAVES][2];
     __shared__ int s_cnt[SWAVES];
     __shared__ long long s_base[2];
     __shared__ int s_batch;
@@ -393,7 +391,6 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         int cls[KPT];
         unsigned xr[KPT], yr[KPT];     // first covered pixel | (number of covered pixels << 16), clipped to the image
         unsigned s_lo = 0xffffffffu, s_hi = 0u;      // covered-pixel bounding box of the small footprints: (ilo | jlo << 16), (ihi | jhi << 16)
-        unsigned m_lo = 0xffffffffu, m_hi = 0u;      // the same for the mid footprints
         int my_counts = 0;                           // mid records | huge records << 16 of this lane
         Camera cam;                                  // (16 scalar registers, live in this phase only)
         float p_small;
@@ -437,7 +434,6 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
             cls[k] = vis ? c_of_p : CLS_NONE;
             const bool is_small = cls[k] == CLS_SMALL, is_mid = cls[k] == CLS_MID;
             s_lo = is_small ? pk_min_u16(s_lo, lo) : s_lo; s_hi = is_small ? pk_max_u16(s_hi, hi) : s_hi;
-            m_lo = is_mid ? pk_min_u16(m_lo, lo) : m_lo; m_hi = is_mid ? pk_max_u16(m_hi, hi) : m_hi;
             my_counts += is_mid ? 1 : ((cls[k] == CLS_HUGE) ? (1 << 16) : 0);
             n_cull += (in_chunk && !vis) ? 1ull : 0ull;
         }
@@ -485,18 +481,11 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
             if (cls[k] != CLS_SMALL) continue;
             const int ilo = (int)(xr[k] & 0xffffu), ihi = ilo + (int)(xr[k] >> 16) - 1;
             const int jlo = (int)(yr[k] & 0xffffu), jhi = jlo + (int)(yr[k] >> 16) - 1;
-            if (ilo < wox || ihi >= wox + WIN || jlo < woy || jhi >= woy + WIN) {
-                cls[k] = CLS_MID; my_counts += 1;
-                m_lo = pk_min_u16(m_lo, (unsigned)ilo | ((unsigned)jlo << 16));
-                m_hi = pk_max_u16(m_hi, (unsigned)ihi | ((unsigned)jhi << 16));
-            }
+            if (ilo < wox || ihi >= wox + WIN || jlo < woy || jhi >= woy + WIN) { cls[k] = CLS_MID; my_counts += 1; }
         }
-        // record counts + offsets and the bounding box of the chunk's MID footprints
+        // record counts + offsets
         const int counts_incl = wave_incl_scan(my_counts, lane);       // both counters at once: <= 128 each per wave
-        const unsigned long long any_mid = __ballot((my_counts & 0xffff) != 0);
-        if (any_mid) { m_lo = wave_pk_min_u16(m_lo); m_hi = wave_pk_max_u16(m_hi); }
         if (lane == 63) s_cnt[wv] = counts_incl;
-        if (lane == 0) { s_mbb[wv][0] = m_lo; s_mbb[wv][1] = m_hi; }
         __syncthreads();
         int counts_before = 0, counts_total = 0;
 #pragma unroll
@@ -516,29 +505,6 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
             if (grab) r_batch = atomicAdd(reinterpret_cast<unsigned *>(&cntp->next_chunk), (unsigned)grab);
             if (mid_total) r_mid = (long long)atomicAdd(&cntp->n_mid, (unsigned long long)mid_total);
             if (huge_total) r_huge = (long long)atomicAdd(&cntp->n_huge, (unsigned long long)huge_total);
-            ap->seg_count[c] = mid_total;
-            if (mid_total) {
-                // covered-pixel bounds [x0, x1] x [y0, y1] stored as (x0, y0, x1 + 1, y1 + 1): kernel M's tile test
-                // bb.x < tile_x1 && bb.z > tile_x0 is then exact for integer tile edges
-                unsigned lo = s_mbb[0][0], hi = s_mbb[0][1];
-#pragma unroll
-                for (int w = 1; w < SWAVES; ++w) { lo = pk_min_u16(lo, s_mbb[w][0]); hi = pk_max_u16(hi, s_mbb[w][1]); }
-                ap->seg_bbox[c] = make_float4((float)(lo & 0xffffu), (float)(lo >> 16), (float)((hi & 0xffffu) + 1u), (float)((hi >> 16) + 1u));
-            }
-        }
-        if (tid == SBLOCK - 1 && mid_total) {
-            // Kernel M's workgroups look only at the chunks of their own image band: one or two appends per chunk here against
-            // a scan of every chunk header by every tile there.  Done by the LAST thread, off the workgroup's critical path
-            // (the returning atomic costs a round trip to L2 that only this wave waits for; s_mbb is not rewritten before
-            // the next chunk's second barrier).  Aggregating the appends per workgroup (one
-            // atomic per workgroup and band) measured slower: +0.15 ms on this kernel for its two extra barriers.
-            unsigned lo = s_mbb[0][0], hi = s_mbb[0][1];
-#pragma unroll
-            for (int w = 1; w < SWAVES; ++w) { lo = pk_min_u16(lo, s_mbb[w][0]); hi = pk_max_u16(hi, s_mbb[w][1]); }
-            CArgs *ap = KA();
-            const int band_h = ap->band_h;
-            const int b0 = (int)(lo >> 16) / band_h, b1 = (int)(hi >> 16) / band_h;
-            for (int b = b0; b <= b1; ++b) ap->band_list[(long long)b * ap->band_cap + atomicAdd(&ap->band_count[b], 1)] = c;
         }
         const int my_mid = my_counts & 0xffff, my_huge = my_counts >> 16;
         const int mid_before = counts_before & 0xffff, huge_before = counts_before >> 16;
@@ -671,7 +637,6 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         if (tid == 0) {
             s_base[0] = r_mid; s_base[1] = r_huge;
             if (grab) s_batch = (int)r_batch;
-            KA()->seg_offset[c] = r_mid;
         }
         __syncthreads();
         if (grab) {
@@ -730,394 +695,6 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
         if (dbg_slots) atomicAdd(&cntp->n_frag_class[1], dbg_slots);
 #endif
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// kernel M: mid footprints (p_small <= P < 64), tile scatter with nearest-mip sampling
-// ---------------------------------------------------------------------------------------------
-
-constexpr int MT = 512;              // threads per workgroup of kernel M (8 waves share tile + LUT)
-#ifndef TSP_M_BRANCHFREE
-#define TSP_M_BRANCHFREE 1
-#endif
-#ifndef TSP_M_QUADROWS
-#define TSP_M_QUADROWS 1
-#endif
-// rows of one channel of kernel M's LDS tile: with the branch-free stepping of a density render a lane up to 7 rows below the
-// tile's last row adds +0 to "its" pixel, so the tile carries 7 rows nobody reads
-constexpr int mtile_rows(int mode, int wc) { return mtile_h(wc) + ((TSP_M_BRANCHFREE && mode != TSP_MODE_RGB && wc == 1) ? 7 : 0); }
-
-// LUT quadrants: the kernel image is a radial function sampled on a grid symmetric about its centre, so every mip level
-// equals its mirror images bit for bit (checked at upload, tsp_set_kernel_mips).  Kernel M then keeps only the top-left
-// quadrant of each level in LDS -- 5.4 KB instead of 21.8 KB -- where that raises the occupancy (rgb), and folds a texel index once per row / column block: i -> min(i, n - 1 - i).
-// (MIPQ_TOTAL, mipq_offset: tsp_pipeline.h)
-// (Round 5 re-measured padded table rows -- a row stride of 8 * odd floats, so that the 8 x 8 lanes of a step read 64 distinct
-// banks -- at 1e9 particles: kernel M 16.4 ms with and without.  The 30 % bank conflicts of its LUT reads are not on its critical
-// path; the natural layout stays.)
-
-// WC = channels accumulated in the LDS tile (1 for a density-only render, else the image's channel count);
-// QUAD = the LUT is mirror-symmetric: quadrant tables
-template <int MODE, int WC, bool QUAD>
-__global__ __launch_bounds__(MT) void splat_mid_kernel(TileArgs a) {
-    constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
-    constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
-    constexpr int MTILE_H = mtile_h(WC);
-    constexpr int MROWS = mtile_rows(MODE, WC);                              // LDS rows per channel: the tile + (branch-free stepping) 7 rows that only ever receive +0
-    extern __shared__ __attribute__((aligned(16))) double smem_d[];
-    double *tile = smem_d;                                                   // [WC][MROWS][MSTR]
-    float *T = reinterpret_cast<float *>(tile + WC * MROWS * MSTR);          // mip pyramid: 5440 floats, or 1360 (quadrants)
-    __shared__ long long s_seg_off[MT];
-    __shared__ int s_seg_cnt[MT];
-    __shared__ int s_wcnt[MT / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int R = a.cam.R;
-    const int tile_id = blockIdx.x / a.split, sp = blockIdx.x % a.split;
-    const int tx0 = (tile_id % a.tiles_x) * TILE, ty0 = (tile_id / a.tiles_x) * MTILE_H;
-    const float fx0 = (float)tx0, fy0 = (float)ty0, fx1 = (float)(tx0 + TILE), fy1 = (float)(ty0 + MTILE_H);
-    if (QUAD) {
-        for (int i = tid; i < MIPQ_TOTAL; i += MT) {
-            const int lvl = i < 1024 ? 0 : (i < 1280 ? 1 : (i < 1344 ? 2 : 3));
-            const int hn = 32 >> lvl, k = i - mipq_offset(lvl);
-            T[i] = a.mips[mip_offset(lvl) + (k / hn) * (2 * hn) + (k % hn)];
-        }
-    } else {
-        for (int i = tid; i < MIP_TOTAL; i += MT) T[i] = a.mips[i];
-    }
-    for (int i = tid; i < WC * MROWS * MSTR; i += MT) tile[i] = 0.0;
-    __syncthreads();
-    const int lx = lane & 7, ly = lane >> 3;
-    unsigned long long n_frag = 0;
-    bool touched = false;
-
-    // The chunks whose mid footprints reach this tile's image band were listed by kernel S (band_list); their headers are
-    // examined 512 at a time (one per lane).  They are dealt to the `split` workgroups of this tile with stride `split`:
-    // every workgroup sees an even sample of the band's chunks (an even share of the tile's work)
-    const int band = ty0 / a.band_h;
-    const int n_list = a.band_count[band];
-    const int *blist = a.band_list + (long long)band * a.band_cap;
-    for (int sbase = 0; sbase * a.split < n_list; sbase += MT) {
-        const int li = (sbase + tid) * a.split + sp;
-        int seg = 0;
-        bool shit = false;
-        int scnt = 0;
-        if (li < n_list) {
-            seg = blist[li];
-            scnt = a.seg_count[seg];
-            const float4 bb = a.seg_bbox[seg];
-            shit = bb.x < fx1 && bb.z > fx0 && bb.y < fy1 && bb.w > fy0;
-        }
-        const unsigned long long smask = __ballot(shit);
-        const int sbefore = __popcll(smask & ((1ull << lane) - 1ull));
-        __syncthreads();                       // previous batch's segment list is no longer read
-        if (lane == 0) s_wcnt[wv] = __popcll(smask);
-        __syncthreads();
-        int wbase = 0, nseg = 0;
-#pragma unroll
-        for (int w = 0; w < MT / 64; ++w) {
-            if (w < wv) wbase += s_wcnt[w];
-            nseg += s_wcnt[w];
-        }
-        if (shit) {
-            s_seg_off[wbase + sbefore] = a.seg_offset[seg];
-            s_seg_cnt[wbase + sbefore] = scnt;
-        }
-        __syncthreads();
-        for (int sidx = 0; sidx < nseg; ++sidx) {
-            const long long off = s_seg_off[sidx];
-            const int cnt = s_seg_cnt[sidx];
-            for (int base = 0; base < cnt; base += MT) {
-                // records are dealt to the waves round-robin (wave w takes records w, w + 8, ...): a segment
-                // holds ~100 records on average, and handing them out in runs of 64 would leave six of the
-                // eight waves idle
-                const int li = base + lane * (MT / 64) + wv;
-                // ---- per lane: one record, its tile-clipped pixel ranges and mip level ----------------
-                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-                float gw1 = 0.f, gw2 = 0.f, g_half = 0.f, g_invP = 0.f;
-                int packed = 0;
-                bool hit = false;
-                if (li < cnt && off + li < a.n_records) {
-                    g = a.geom[off + li];
-                    g_half = 0.5f * g.z;
-                    if ((g.x + g_half > fx0) && (g.x - g_half < fx1) && (g.y + g_half > fy0) && (g.y - g_half < fy1)) {
-                        int ilo, ihi, jlo, jhi;
-                        cover_range(g.x, g_half, R, ilo, ihi);
-                        cover_range(g.y, g_half, R, jlo, jhi);
-                        ilo = max(ilo, tx0) - tx0; ihi = min(ihi, tx0 + TILE - 1) - tx0;
-                        jlo = max(jlo, ty0) - ty0; jhi = min(jhi, ty0 + MTILE_H - 1) - ty0;
-                        if (ilo <= ihi && jlo <= jhi) {
-                            hit = true;
-                            gw1 = a.w[(off + li) * NW];
-                            if (NW == 2) gw2 = a.w[(off + li) * NW + 1];
-                            g_invP = 1.0f / g.z;
-                            const int lvl = max(level_for(g.z), 0);
-                            packed = ilo | (ihi << 6) | (jlo << 12) | (jhi << 18) | (lvl << 24);
-                        }
-                    }
-                }
-                unsigned long long mask = __ballot(hit);
-                touched = touched || (mask != 0ull);
-                // ---- per wave: one footprint at a time, its parameters broadcast into scalar registers ----
-                while (mask) {
-                    const int src = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const float q_pcx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.x), src));
-                    const float q_pcy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.y), src));
-                    const float q_half = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_half), src));
-                    const float q_invP = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_invP), src));
-                    const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.w), src));
-                    const float w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gw1), src));
-                    const float w2 = (NW == 2) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gw2), src)) : 0.0f;
-                    const int pk = __builtin_amdgcn_readlane(packed, src);
-                    const int ilo = pk & 63, ihi = (pk >> 6) & 63, jlo = (pk >> 12) & 63, jhi = (pk >> 18) & 63, lvl = pk >> 24;
-                    const int n = 64 >> lvl, toff = QUAD ? mipq_offset(lvl) : mip_offset(lvl), tshift = QUAD ? 5 - lvl : 6 - lvl;      // LUT row stride = 1 << tshift
-                  if constexpr (TSP_M_QUADROWS && MODE != TSP_MODE_RGB && WC == 1) {
-                    // Branch-free 8 x 8 stepping with the row set-up SHARED across the quad.  A lane (ly, lx) of the 8 x 8 step draws pixel
-                    // rows jlo + 8 rb + ly (rb = 0 .. 3) of the footprint: in the form below every lane worked out the LUT row and the
-                    // weight of each of its <= 4 rows itself -- the same ~14 instructions per row block on all eight lanes of a pixel row,
-                    // and at 1e9 particles 7e7 (footprint, tile) pairs made that most of this kernel's vector instructions.  Here lane
-                    // (ly, lx) evaluates ONE row, that of row block lx & 3: the four lanes of a quad hold the LUT row addresses and
-                    // weights of the four row blocks of their ly, and a row block's value reaches the quad as the DPP operand
-                    // (quad_perm) of the instruction that uses it (the address add, the multiply): no extra instruction, no LDS.
-                    // The same float32 operations on the same operands: bit-identical images.  1e9 particles: 14.35 -> 14.0 ms,
-                    // 1e8: 4.43 -> 4.22.  (Sharing the COLUMN set-up too -- lane l evaluates column ilo + l once per footprint, a
-                    // step fetches the value of lane 8 s + lx with ds_bpermute_b32 -- halved the kernel's vector instructions and
-                    // measured SLOWER, 15.4 ms: the kernel is bound by its LDS pipe, and that put one more operation per step on it.)
-                    constexpr int NRB_MAX = MTILE_H / 8;
-                    static_assert(NRB_MAX <= 4, "a quad carries four row blocks");
-                    const int nrb = ((jhi - jlo) >> 3) + 1;                 // row blocks the footprint touches in this tile (wave-uniform)
-                    typedef const __attribute__((address_space(3))) float LdsF;
-                    const int T_lds = (int)(unsigned)(unsigned long long)(LdsF *)T;      // (an LDS pointer is a 32-bit byte address)
-                    int trow_q; float w_q;
-                    {
-                        const int j = jlo + 8 * (lx & 3) + ly;
-                        const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
-                        int ty = nearest_index((dy + q_half) * q_invP, n);
-                        if (QUAD) ty = min(ty, n - 1 - ty);
-                        trow_q = T_lds + (toff + (ty << tshift)) * 4;          // LDS address of the LUT row
-                        w_q = (j <= jhi) ? w0 : 0.0f;                       // +0 below the footprint's last row (the tile carries 7 rows for those lanes)
-                    }
-                    auto lut_column = [&](int i) -> int {                   // byte offset of pixel column i's texel in a LUT row
-                        const float dx = ((float)(tx0 + i) + 0.5f) - q_pcx;
-                        int tx = nearest_index((dx + q_half) * q_invP, n);
-                        if (QUAD) tx = min(tx, n - 1 - tx);
-                        return tx * 4;
-                    };
-                    // (DPP operands must not have been written by the two preceding VALU instructions: pinned here, then two wait states)
-                    asm volatile("" : "+v"(trow_q), "+v"(w_q));
-                    asm volatile("s_nop 1");
-                    double *dcol0 = tile + (jlo + ly) * MSTR + ilo + lx;      // this lane's pixel of row block 0, step 0
-                    auto draw = [&](auto nrb_c) {
-                        constexpr int NRB = decltype(nrb_c)::value;
-#pragma unroll
-                        for (int s = 0; s < TILE / 8; ++s) {
-                            const int ib = ilo + 8 * s;
-                            if (ib > ihi) break;
-                            const int txs = lut_column(ib + lx);
-                            auto body = [&](auto partial_c) {
-                                constexpr bool PARTIAL = decltype(partial_c)::value;
-                                float kv[NRB];
-#pragma unroll
-                                for (int rb = 0; rb < NRB; ++rb) {
-                                    int o;
-                                    if (rb == 0) asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(0) : "=v"(o) : "v"(trow_q), "v"(txs));
-                                    if (rb == 1) asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(1) : "=v"(o) : "v"(trow_q), "v"(txs));
-                                    if (rb == 2) asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(2) : "=v"(o) : "v"(trow_q), "v"(txs));
-                                    if (rb == 3) asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(3) : "=v"(o) : "v"(trow_q), "v"(txs));
-                                    kv[rb] = *reinterpret_cast<LdsF *>(o);
-                                }
-                                const bool colok = ib + lx <= ihi;
-#pragma unroll
-                                for (int rb = 0; rb < NRB; ++rb) {
-                                    float val;
-                                    if (rb == 0) asm volatile("v_mul_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(0) : "=v"(val) : "v"(w_q), "v"(kv[rb]));
-                                    if (rb == 1) asm volatile("v_mul_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(1) : "=v"(val) : "v"(w_q), "v"(kv[rb]));
-                                    if (rb == 2) asm volatile("v_mul_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(2) : "=v"(val) : "v"(w_q), "v"(kv[rb]));
-                                    if (rb == 3) asm volatile("v_mul_f32_dpp %0, %1, %2 " TSP_DPP_QUAD(3) : "=v"(val) : "v"(w_q), "v"(kv[rb]));
-                                    if (PARTIAL) { val = colok ? val : 0.0f; asm volatile("" : "+v"(val)); }      // (the select acts on the float32 product)
-                                    latomic_add(dcol0 + 8 * s + rb * 8 * MSTR, val);
-                                }
-                            };
-                            // (wave-uniform) only the last step of a footprint can hold uncovered columns
-                            if (ib + 7 <= ihi) body(std::false_type()); else body(std::true_type());
-                        }
-                    };
-                    if (NRB_MAX == 4 && nrb == 4) draw(std::integral_constant<int, NRB_MAX>());
-                    else if (NRB_MAX >= 3 && nrb == 3) draw(std::integral_constant<int, (NRB_MAX >= 3 ? 3 : 1)>());
-                    else if (nrb == 2) draw(std::integral_constant<int, 2>());
-                    else draw(std::integral_constant<int, 1>());
-                  } else if constexpr (TSP_M_BRANCHFREE && MODE != TSP_MODE_RGB && WC == 1) {
-                    // Branch-free 8 x 8 stepping (round 5: density 16.7 -> 15.4 -> 15.1 ms at 1e9 particles; rgb -- three atomics per step on
-                    // 16-row tiles -- measured slower and keeps the masked form below).  Per 8-row block rb this lane's LUT row (byte
-                    // offset) and its WEIGHT are formed once per footprint: the footprint's weight where the lane's pixel row is covered,
-                    // +0 where it is not -- so a step multiplies, converts and adds with the whole wave, and a lane below the footprint's
-                    // last row adds +0 to its own pixel (x + 0 is x) of the tile, which carries MPAD extra rows for it.  No exec-mask
-                    // save / branch / restore per block (those were half of this kernel's 5.4e9 scalar instructions at 1e9 particles);
-                    // the LUT reads of a column step are issued together and awaited once; the LDS addresses of a step's row blocks
-                    // differ by immediates.  Only the LAST column step of a footprint can hold uncovered columns: it alone selects.
-                    constexpr int NRB_MAX = MTILE_H / 8;
-                    const int nrb = ((jhi - jlo) >> 3) + 1;                 // row blocks the footprint touches in this tile (wave-uniform)
-                    const char *Tb = reinterpret_cast<const char *>(T);
-                    char *rowp = reinterpret_cast<char *>(tile) + ((jlo + ly) * MSTR) * 8;      // this lane's pixel row of block 0
-                    auto draw = [&](auto nrb_c) {
-                        constexpr int NRB = decltype(nrb_c)::value;
-                        // (only the row blocks the footprint touches are prepared: this set-up, not the stepping, was most of the
-                        // kernel's vector instructions -- 7e7 (footprint, tile) pairs at 1e9 particles)
-                        int trowB[NRB];
-                        float wv0[NRB], wv1[NRB];
-#pragma unroll
-                        for (int rb = 0; rb < NRB; ++rb) {
-                            const int j = jlo + 8 * rb + ly;
-                            const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
-                            int ty = nearest_index((dy + q_half) * q_invP, n);
-                            if (QUAD) ty = min(ty, n - 1 - ty);
-                            trowB[rb] = (toff + (ty << tshift)) * 4;
-                            wv0[rb] = (j <= jhi) ? w0 : 0.0f;
-                            wv1[rb] = (j <= jhi) ? w1 : 0.0f;       // (its own +0: val * w1 with val = 0 would be NaN for a non-finite quantity)
-                        }
-                        auto step = [&](int ib, auto partial_c) {
-                            constexpr bool PARTIAL = decltype(partial_c)::value;
-                            const int i = ib + lx;
-                            const float dx = ((float)(tx0 + i) + 0.5f) - q_pcx;
-                            int tx = nearest_index((dx + q_half) * q_invP, n);
-                            if (QUAD) tx = min(tx, n - 1 - tx);
-                            const bool colok = i <= ihi;
-                            float kv[NRB];
-#pragma unroll
-                            for (int rb = 0; rb < NRB; ++rb) kv[rb] = *reinterpret_cast<const float *>(Tb + trowB[rb] + tx * 4);
-                            double *dcol = reinterpret_cast<double *>(rowp + i * 8);
-#pragma unroll
-                            for (int rb = 0; rb < NRB; ++rb) {
-                                float val = kv[rb] * wv0[rb];
-                                float val1 = (WC > 1) ? val * wv1[rb] : 0.0f;       // canonical order (k w0) q in a covered row, 0 * 0 in an uncovered one
-                                if (PARTIAL) {      // the select acts on the float32 products, pinned before the conversions
-                                    val = colok ? val : 0.0f; asm volatile("" : "+v"(val));
-                                    if (WC > 1) { val1 = colok ? val1 : 0.0f; asm volatile("" : "+v"(val1)); }
-                                }
-                                double *d = dcol + rb * 8 * MSTR;
-                                latomic_add(d, val);
-                                if (WC > 1) latomic_add(d + MROWS * MSTR, val1);
-                            }
-                        };
-                        // (two channels on 16-row tiles: few steps per (footprint, tile) pair -- one loop that always selects measured
-                        // faster than the split: 1e7 weighted 2.05 against 2.34 ms)
-                        int ib = ilo;
-                        if (WC == 1) for (; ib + 7 <= ihi; ib += 8) step(ib, std::false_type());
-                        for (; ib <= ihi; ib += 8) step(ib, std::true_type());
-                    };
-                    if (NRB_MAX == 4 && nrb == 4) draw(std::integral_constant<int, NRB_MAX>());
-                    else if (NRB_MAX >= 3 && nrb == 3) draw(std::integral_constant<int, (NRB_MAX >= 3 ? 3 : 1)>());
-                    else if (nrb == 2) draw(std::integral_constant<int, 2>());
-                    else draw(std::integral_constant<int, 1>());
-                  } else if constexpr (TSP_M_BRANCHFREE && MODE != TSP_MODE_RGB) {
-                    // Two channels (16-row tiles, few steps per (footprint, tile) pair): the first branch-free form -- row and column
-                    // masks combined per step (one scalar AND), the products selected to +0, rows wrapped into the tile instead of
-                    // padding it -- measured faster than the form above here (1e7 weighted: 2.00 against 2.34 ms; masked: 2.06)
-                    constexpr int NRB_MAX = MTILE_H / 8;
-                    const int nrb = ((jhi - jlo) >> 3) + 1;                 // row blocks the footprint touches in this tile (wave-uniform)
-                    const char *Tb = reinterpret_cast<const char *>(T);
-                    char *tileb = reinterpret_cast<char *>(tile);
-                    auto draw = [&](auto nrb_c) {
-                        constexpr int NRB = decltype(nrb_c)::value;
-                        int trowB[NRB], rowA[NRB];
-                        bool rowok[NRB];                                    // (lane masks in scalar registers)
-#pragma unroll
-                        for (int rb = 0; rb < NRB; ++rb) {
-                            const int j = jlo + 8 * rb + ly;
-                            const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
-                            int ty = nearest_index((dy + q_half) * q_invP, n);
-                            if (QUAD) ty = min(ty, n - 1 - ty);
-                            trowB[rb] = (toff + (ty << tshift)) * 4;
-                            rowA[rb] = (j & (MTILE_H - 1)) * (MSTR * 8);
-                            rowok[rb] = j <= jhi;
-                        }
-                        for (int ib = ilo; ib <= ihi; ib += 8) {
-                            const int i = ib + lx;
-                            const float dx = ((float)(tx0 + i) + 0.5f) - q_pcx;
-                            int tx = nearest_index((dx + q_half) * q_invP, n);
-                            if (QUAD) tx = min(tx, n - 1 - tx);
-                            const bool colok = i <= ihi;
-                            float kv[NRB];
-#pragma unroll
-                            for (int rb = 0; rb < NRB; ++rb) kv[rb] = *reinterpret_cast<const float *>(Tb + trowB[rb] + tx * 4);
-#pragma unroll
-                            for (int rb = 0; rb < NRB; ++rb) {
-                                const bool ok = colok && rowok[rb];
-                                double *d = reinterpret_cast<double *>(tileb + rowA[rb] + i * 8);
-                                // the select acts on the float32 product (one v_cndmask), pinned before the conversion
-                                auto pick = [&](float v) { float r = ok ? v : 0.0f; asm volatile("" : "+v"(r)); return r; };
-                                if (MODE == TSP_MODE_RGB) {     // the counter channel is summed by add_rect_counts()
-                                    latomic_add(d, pick(kv[rb] * w0)); latomic_add(d + MROWS * MSTR, pick(kv[rb] * w1));
-                                    latomic_add(d + 2 * MROWS * MSTR, pick(kv[rb] * w2));
-                                } else {
-                                    const float val = kv[rb] * w0;
-                                    latomic_add(d, pick(val));
-                                    if (WC > 1) latomic_add(d + MROWS * MSTR, pick(val * w1));
-                                }
-                            }
-                        }
-                    };
-                    if (NRB_MAX == 4 && nrb == 4) draw(std::integral_constant<int, NRB_MAX>());
-                    else if (NRB_MAX >= 3 && nrb == 3) draw(std::integral_constant<int, (NRB_MAX >= 3 ? 3 : 1)>());
-                    else if (nrb == 2) draw(std::integral_constant<int, 2>());
-                    else draw(std::integral_constant<int, 1>());
-                  } else {
-                    // texel row of this lane's pixel row in each 8-row block of the footprint (the tile is 32 rows: <= 4 blocks)
-                    int trow[MTILE_H / 8];
-#pragma unroll
-                    for (int rb = 0; rb < MTILE_H / 8; ++rb) {
-                        trow[rb] = -1;
-                        if (jlo + 8 * rb <= jhi) {
-                            const int j = jlo + 8 * rb + ly;
-                            const float dy = ((float)(ty0 + j) + 0.5f) - q_pcy;
-                            int ty = nearest_index((dy + q_half) * q_invP, n);
-                            if (QUAD) ty = min(ty, n - 1 - ty);
-                            trow[rb] = (j <= jhi) ? toff + (ty << tshift) : -1;
-                        }
-                    }
-                    for (int ib = ilo; ib <= ihi; ib += 8) {
-                        const int i = ib + lx;
-                        const float dx = ((float)(tx0 + i) + 0.5f) - q_pcx;
-                        int tx = nearest_index((dx + q_half) * q_invP, n);
-                        if (QUAD) tx = min(tx, n - 1 - tx);
-                        double *dcol = tile + (jlo + ly) * MSTR + i;
-#pragma unroll
-                        for (int rb = 0; rb < MTILE_H / 8; ++rb) {
-                            if (jlo + 8 * rb > jhi) break;
-                            if (i <= ihi && trow[rb] >= 0) {
-                                const float kv = T[trow[rb] + tx];
-                                double *d = dcol + rb * 8 * MSTR;
-                                if (MODE == TSP_MODE_RGB) {     // the counter channel is summed by add_rect_counts()
-                                    latomic_add(d, kv * w0); latomic_add(d + MROWS * MSTR, kv * w1);
-                                    latomic_add(d + 2 * MROWS * MSTR, kv * w2);
-                                } else {      // (skipping the exactly-zero corner texels lane by lane measured slower: 5.5 -> 6.0 ms)
-                                    const float val = kv * w0;
-                                    latomic_add(d, val);
-                                    if (WC > 1) latomic_add(d + MROWS * MSTR, val * w1);
-                                }
-                            }
-                        }
-                    }
-                  }
-                    if (a.count_frag && lane == 0) n_frag += (unsigned long long)((ihi - ilo + 1) * (jhi - jlo + 1));
-                }
-            }
-        }
-    }
-    const int any = __syncthreads_or(touched ? 1 : 0);
-    if (any) {
-        for (int idx = tid; idx < TILE * MTILE_H; idx += MT) {
-            const int wy = idx / TILE, wx = idx % TILE;
-            const int gx = tx0 + wx, gy = ty0 + wy;
-            if (gx < R && gy < R) {
-#pragma unroll
-                for (int c = 0; c < WC; ++c) {
-                    const double v = tile[c * MROWS * MSTR + wy * MSTR + wx];
-                    if (v != 0.0) gatomic_add(a.img + ((size_t)gy * R + gx) * C + c, v);
-                }
-            }
-        }
-    }
-    if (a.count_frag && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[1], n_frag); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1242,30 +819,13 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         TSP_HIP(hipMalloc((void **)&ws.range_prefix, ws.range_capacity * sizeof(int64_t)));
     }
     TSP_HIP(hipMemcpyAsync(ws.range_prefix, pack.data(), pack.size() * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    // per-chunk segment table
-    if (ws.seg_capacity < n_chunks) {
-        if (ws.seg_count) TSP_HIP(hipFree(ws.seg_count));
-        if (ws.seg_offset) TSP_HIP(hipFree(ws.seg_offset));
-        if (ws.seg_bbox) TSP_HIP(hipFree(ws.seg_bbox));
+    // the list of chunks that survive culling (+ the per-workgroup counts of the culling pass behind it)
+    if (ws.chunk_capacity < n_chunks) {
         if (ws.alive_list) TSP_HIP(hipFree(ws.alive_list));
-        ws.seg_capacity = (int64_t)n_chunks + n_chunks / 4 + 64;
-        TSP_HIP(hipMalloc((void **)&ws.alive_list, (ws.seg_capacity + ws.seg_capacity / 256 + 2) * sizeof(int)));
-        TSP_HIP(hipMalloc((void **)&ws.seg_count, ws.seg_capacity * sizeof(int)));
-        TSP_HIP(hipMalloc((void **)&ws.seg_offset, ws.seg_capacity * sizeof(long long)));
-        TSP_HIP(hipMalloc((void **)&ws.seg_bbox, ws.seg_capacity * sizeof(float4)));
+        ws.alive_list = nullptr;
+        ws.chunk_capacity = (int64_t)n_chunks + n_chunks / 4 + 64;
+        TSP_HIP(hipMalloc((void **)&ws.alive_list, (ws.chunk_capacity + ws.chunk_capacity / 256 + 2) * sizeof(int)));
     }
-    {   // per band: at most every chunk once
-        const int64_t need = (int64_t)n_chunks + 64;
-        if (ws.band_capacity < need) {
-            if (ws.band_list) TSP_HIP(hipFree(ws.band_list));
-            ws.band_list = nullptr;
-            ws.band_capacity = need + need / 4;
-            TSP_HIP(hipMalloc((void **)&ws.band_list, (size_t)NBANDS * ws.band_capacity * sizeof(int)));
-        }
-    }
-    if (!ws.band_count) TSP_HIP(hipMalloc((void **)&ws.band_count, NBANDS * sizeof(int)));
-    // image bands of kernel M's chunk lists: at most NBANDS, each a whole number of 32-row tile rows
-    const int band_h = (((ctx->R + NBANDS - 1) / NBANDS + 31) / 32) * 32;
     // record lists: start modest, grow to the exact need when a frame overflows (rare)
     int rc;
     if ((rc = ensure_weights(ctx, MODE == TSP_MODE_RGB))) return rc;      // m / h^2 (rgb / h^2): once per upload, not per frame
@@ -1284,39 +844,14 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
 
     Particles parts = ctx->p;
     if (!ctx->use_quantity) parts.q = nullptr;
-    const int tiles_x = (ctx->R + TILE - 1) / TILE;
     const bool second_channel = (MODE == TSP_MODE_DEPTH) || (MODE == TSP_MODE_RGB) || (ctx->p.q != nullptr && ctx->use_quantity);
     const int WCr = (MODE == TSP_MODE_RGB) ? 4 : (second_channel ? 2 : 1);
     const int WIN = (WCr == 1) ? WinSize<1>::value : WinSize<C>::value;
     const size_t smem_s = (size_t)WCr * WIN * WIN * sizeof(double) + T23_FLOATS * sizeof(float);
-    constexpr int WCM = (MODE == TSP_MODE_RGB) ? 3 : C;      // LDS tile channels of kernel M (rgb: values only)
-    const int mth = mtile_h(WCr == 1 ? 1 : WCM);
-    // quadrant tables pay where LDS limits the occupancy: rgb (three channels: 2 -> 4 workgroups per CU, 21.0 -> 17.1 ms);
-    // a density render already fits three workgroups and measured slower with four (7.6 vs 7.2 ms: LDS-atomic-bound)
-    const bool quad = ctx->lut_mirror_symmetric && MODE == TSP_MODE_RGB;
-    const size_t smem_m = (size_t)(WCr == 1 ? 1 : WCM) * mtile_rows(MODE, WCr == 1 ? 1 : WCM) * MSTR * sizeof(double) + (quad ? MIPQ_TOTAL : MIP_TOTAL) * sizeof(float) + (size_t)ctx->debug_extra_lds;
-    const int mtiles_y = (ctx->R + mth - 1) / mth;
     if (!(ctx->kernel_attr_done & (1u << MODE))) {
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)C * WinSize<C>::value * WinSize<C>::value * sizeof(double) + T23_FLOATS * sizeof(float))));
         TSP_HIP(hipFuncSetAttribute((const void *)splat_stream_kernel<MODE, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)WinSize<1>::value * WinSize<1>::value * sizeof(double) + T23_FLOATS * sizeof(float))));
         ctx->kernel_attr_done |= 1u << MODE;
-        ctx->mid_attr_extra[MODE] = -1;
-    }
-    if (ctx->mid_attr_extra[MODE] != ctx->debug_extra_lds) {
-        // the dynamic-LDS limit of kernel M follows the debug_extra_lds option (a measurement aid that lowers its occupancy)
-        const int lds_m = (int)((size_t)C * (32 + 7) * MSTR * sizeof(double) + MIP_TOTAL * sizeof(float)) + ctx->debug_extra_lds;
-        const void *fns[4] = {(const void *)splat_mid_kernel<MODE, WCM, false>, (const void *)splat_mid_kernel<MODE, 1, false>,
-                              (const void *)splat_mid_kernel<MODE, WCM, true>, (const void *)splat_mid_kernel<MODE, 1, true>};
-        for (const void *fn : fns) {
-            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_m);
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                set_error("kernel M cannot take %d bytes of dynamic LDS (%s)%s", lds_m, hipGetErrorString(e),
-                          ctx->debug_extra_lds > 0 ? ": lower the debug_extra_lds option" : "");
-                return ctx->debug_extra_lds > 0 ? TSP_EINVAL : TSP_EHIP;
-            }
-        }
-        ctx->mid_attr_extra[MODE] = ctx->debug_extra_lds;
     }
 
     // Chunk culling (option chunk_cull, on by default): one small kernel lists the chunks whose bounds can reach the view; kernel S
@@ -1333,7 +868,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         CullArgs ca;
         ca.ranges = ws.range_prefix; ca.n_ranges = n_ranges; ca.n_chunks = n_chunks; ca.cam = cam;
         ca.bounds = ws.block_bounds; ca.n_particles = ctx->p.n; ca.alive = ws.alive_list; ca.info = ws.cull_info;
-        ca.wg_count = ws.alive_list + ws.seg_capacity;          // (the list's allocation carries the per-workgroup counts behind it)
+        ca.wg_count = ws.alive_list + ws.chunk_capacity;          // (the list's allocation carries the per-workgroup counts behind it)
         const int n_wg = (n_chunks + 255) / 256;
         hipLaunchKernelGGL(chunk_cull_kernel<0>, dim3(n_wg), dim3(256), 0, st, ca);
         hipLaunchKernelGGL(chunk_cull_scan_kernel, dim3(1), dim3(1024), 0, st, ca.wg_count, n_wg, ws.cull_info);
@@ -1369,9 +904,6 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         sa.cam = cam; sa.mips = ctx->mips; sa.img = ctx->image64;
         sa.mid_geom = (float4 *)ws.mid_geom; sa.mid_w = (float *)ws.mid_w; sa.mid_capacity = ws.mid_capacity;
         sa.huge_geom = (float4 *)ws.huge_geom; sa.huge_w = (float *)ws.huge_w; sa.huge_capacity = ws.huge_capacity;
-        sa.seg_count = ws.seg_count; sa.seg_offset = ws.seg_offset; sa.seg_bbox = ws.seg_bbox;
-        sa.band_count = ws.band_count; sa.band_list = ws.band_list; sa.band_cap = ws.band_capacity; sa.band_h = band_h;
-        TSP_HIP(hipMemsetAsync(ws.band_count, 0, NBANDS * sizeof(int), st));
         sa.cnt = ctx->counters; sa.p_small = ctx->p_small;
         sa.count_frag = ctx->count_fragments ? 1 : 0;
         sa.emit_small = (attempt == 0 && !ctx->debug_no_raster) ? 1 : 0;
@@ -1411,38 +943,22 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         TSP_HIP(hipStreamSynchronize(st));
     }
     TileArgs ta;
-    ta.seg_count = ws.seg_count; ta.seg_offset = ws.seg_offset; ta.seg_bbox = ws.seg_bbox; ta.n_chunks = n_chunks;
-    ta.band_count = ws.band_count; ta.band_list = ws.band_list; ta.band_cap = ws.band_capacity; ta.band_h = band_h;
-    ta.cam = cam; ta.mips = ctx->mips; ta.img = ctx->image64; ta.cnt = ctx->counters; ta.tiles_x = tiles_x;
+    ta.cam = cam; ta.mips = ctx->mips; ta.img = ctx->image64; ta.cnt = ctx->counters; ta.tiles_x = 0; ta.split = 1;
     ta.count_frag = ctx->count_fragments ? 1 : 0;
     ta.hband_count = nullptr; ta.hband_stride = 0; ta.hband_base = nullptr; ta.n_tiles = 0; ta.item_tile = nullptr; ta.item_base = nullptr;
     // corner culling is exact for the value channels; the rgb counter channel (which also counts zero-valued
     // fragments) is not touched by kernel H2 at all: add_rect_counts() sums the footprint rectangles instead
     ta.disc_k2 = (ctx->lut_zero_outside_disc && !ctx->count_fragments) ? 0.5235f * 0.5235f : 0.0f;
-    // Kernel M (LDS-atomic-bound) and kernel H2 (VALU-bound) only depend on kernel S and add into the
-    // float64 image with atomics, so they run concurrently on two streams and share the CUs.
+    // Kernels G and H2 only depend on kernel S and add into the float64 image with atomics: option overlap_mid_huge runs them on
+    // two streams (no gain measured: both are bound by the vector units).
     hipStream_t st_mid = ctx->overlap_mid_huge ? ctx->stream2 : st;
     if (ctx->overlap_mid_huge) {
         TSP_HIP(hipEventRecord(ctx->ev[8], st));
         TSP_HIP(hipStreamWaitEvent(st_mid, ctx->ev[8], 0));
     }
     TSP_HIP(hipEventRecord(ctx->ev[4], st_mid));
-    if (hc.n_mid > 0 && ctx->mid_variant == 1 && mid_gather_fits(ctx->R, MODE, second_channel)) {
+    if (hc.n_mid > 0) {
         if ((rc = launch_mid_gather(ctx, ta, MODE, second_channel, (const float4 *)ws.mid_geom, (const float *)ws.mid_w, (long long)hc.n_mid, st_mid))) return rc;
-    } else if (hc.n_mid > 0) {
-        ta.geom = (const float4 *)ws.mid_geom; ta.w = (const float *)ws.mid_w; ta.n_records = (long long)hc.n_mid;
-        ta.split = std::max(1, ctx->mid_split * mth / 32);     // the same number of workgroups per image area for both tile heights
-        // (round 5, 2.5e7 records: 48 / 64 / 96 / 128 / 192 workgroups per tile -> 17.0 / 15.7 / 15.3 / 14.9 / 14.6 ms; 3.3e6 records: flat from 64)
-        if ((long long)hc.n_mid >= 16000000ll && ctx->mid_split == 128) ta.split = ta.split * 3 / 2;
-        // a small render block (an interactive frame's first 1e5 particles leave ~3e4 records) does not need 65 536
-        // workgroups that each load the LUT: fewer splits in proportion below 2^18 records
-        if ((long long)hc.n_mid < (1ll << 18)) ta.split = std::max(4, (int)((long long)ta.split * (long long)hc.n_mid >> 18));
-        const dim3 grid_m(tiles_x * mtiles_y * ta.split);
-        if (WCr == 1 && quad) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1, true>), grid_m, dim3(MT), smem_m, st_mid, ta);
-        else if (WCr == 1) hipLaunchKernelGGL((splat_mid_kernel<MODE, 1, false>), grid_m, dim3(MT), smem_m, st_mid, ta);
-        else if (quad) hipLaunchKernelGGL((splat_mid_kernel<MODE, WCM, true>), grid_m, dim3(MT), smem_m, st_mid, ta);
-        else hipLaunchKernelGGL((splat_mid_kernel<MODE, WCM, false>), grid_m, dim3(MT), smem_m, st_mid, ta);
-        TSP_HIP(hipGetLastError());
     }
     TSP_HIP(hipEventRecord(ctx->ev[5], st_mid));
     TSP_HIP(hipEventRecord(ctx->ev[9], st));
