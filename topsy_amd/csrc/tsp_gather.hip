@@ -376,14 +376,13 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 // -- two vector instructions and a 4-byte LDS read per 64 pixels, against a multiply, a float64 conversion and a 9-clock ds_add_f64 per
 // 64 pixels (plus their share of the row / column set-up) in the scatter kernel M, whose LDS atomics bound it.
 // Records: the mid list binned by 64-row image band (bin_records), dealt to the `split` workgroups of a tile as in H2.
-constexpr int GCHUNK_MAX = 2048;          // records per work item of kernel G (fewer for short lists: enough items to fill the device)
+constexpr int GCHUNK_MAX = 1024;          // records per work item of kernel G (fewer for short lists: enough items to fill the device)
 constexpr int G_LDS_TILES = 8192;         // the binning passes keep their tile counters in LDS up to this many tiles (global atomics beyond)
 
 template <int MODE, int NACC, int HR, int OCC, bool QUAD, bool CNT>
 __global__ __launch_bounds__(H2T, OCC) void splat_mid_gather_kernel(TileArgs a) {
     constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
     constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
-    constexpr int TW = 2 * 64, TH = 2 * HR;
     constexpr int NG = HR / 4;
     static_assert(HR == 16 || HR == 32, "rows per wave strip");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -398,11 +397,14 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mid_gather_kernel(TileArgs a) 
 
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int R = a.cam.R;
-    // this workgroup's work item (the launch is sized for the largest possible number of items)
-    if ((int)blockIdx.x >= a.item_base[a.n_tiles]) return;
-    const int tile_id = a.item_tile[blockIdx.x];
-    const int chunk = (int)blockIdx.x - a.item_base[tile_id];
-    const int tx0 = (tile_id % a.tiles_x) * TW, ty0 = (tile_id / a.tiles_x) * TH;
+    // every WAVE draws its own work item: item_records consecutive records of one strip's bin (four items per workgroup, which
+    // shares the LUT; the items of a launch are equal in size, so its waves end together and their slots refill as whole workgroups)
+    const int n_items = a.item_base[a.n_tiles];
+    if ((int)blockIdx.x * (H2T / 64) >= n_items) return;
+    const int item = min((int)blockIdx.x * (H2T / 64) + wv, n_items - 1);
+    const bool idle_wave = (int)blockIdx.x * (H2T / 64) + wv >= n_items;       // (the last workgroup may have fewer than four items)
+    const int strip = a.item_tile[item];
+    const int chunk = item - a.item_base[strip];
     if (QUAD) {
         for (int i = tid; i < MIPQ_TOTAL; i += H2T) {
             const int lvl = i < 1024 ? 0 : (i < 1280 ? 1 : (i < 1344 ? 2 : 3));
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mid_gather_kernel(TileArgs a) 
     }
     int *rt = rt_all + wv * 64;
     const int *rt_quad = rt + (lane & 3);
-    const int sx = tx0 + 64 * (wv & 1), sy = ty0 + HR * (wv >> 1);
+    const int sx = (strip % a.tiles_x) * 64, sy = (strip / a.tiles_x) * HR;
     const float sx0 = (float)sx, sx1 = (float)(sx + 64), sy0 = (float)sy, sy1 = (float)(sy + HR);
     const float pxc = (sx + lane < R) ? (float)(sx + lane) + 0.5f : __builtin_inff();
     const int myrow = lane & (HR - 1);
@@ -428,12 +430,12 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mid_gather_kernel(TileArgs a) 
         for (int c = 0; c < NACC; ++c) acc[p][c] = 0.0f;
     unsigned long long n_frag = 0;
     __syncthreads();                                       // the only workgroup barrier
-    if (sx >= R || sy >= R) return;
+    if (idle_wave) return;
 
-    const size_t first = (size_t)a.hband_base[tile_id] + (size_t)chunk * a.item_records;
+    const size_t first = (size_t)a.hband_base[strip] + (size_t)chunk * a.item_records;
     const float4 *geom = a.geom + first;
     const float *wts = a.w + first * NW;
-    const unsigned n_rec = (unsigned)min(a.item_records, a.hband_count[tile_id] - chunk * a.item_records);
+    const unsigned n_rec = (unsigned)min(a.item_records, a.hband_count[strip] - chunk * a.item_records);
     auto fetch = [&](unsigned b0, float4 &g, float &gw1, float &gw2) {      // records b0 + lane of the item (one per lane)
         const unsigned ri = b0 + lane;
         g = make_float4(0.f, 0.f, 0.f, 0.f); gw1 = gw2 = 0.0f;
@@ -662,8 +664,8 @@ __device__ __forceinline__ TileSpan tile_span(const float4 g, int R, int th, int
     const float half = 0.5f * g.z, xl = g.x - half - 1.0f, xh = g.x + half + 1.0f, yl = g.y - half - 1.0f, yh = g.y + half + 1.0f;
     // (non-finite or off-image squares: no tile; kernel S emits only records that cover a pixel)
     if (xh >= 0.0f && xl < (float)R && yh >= 0.0f && yl < (float)R && xl == xl && xh == xh && yl == yl && yh == yh) {
-        s.x0 = max(0, (int)__builtin_floorf(fmaxf(xl, 0.0f) * (1.0f / 128.0f)));
-        s.x1 = min(tiles_x - 1, (int)__builtin_floorf(fminf(xh, (float)R) * (1.0f / 128.0f)));
+        s.x0 = max(0, (int)__builtin_floorf(fmaxf(xl, 0.0f) * (1.0f / 64.0f)));
+        s.x1 = min(tiles_x - 1, (int)__builtin_floorf(fminf(xh, (float)R) * (1.0f / 64.0f)));
         s.y0 = max(0, (int)__builtin_floorf(fmaxf(yl, 0.0f) / (float)th));
         s.y1 = min(tiles_y - 1, (int)__builtin_floorf(fminf(yh, (float)R) / (float)th));
     }
@@ -722,8 +724,8 @@ __global__ __launch_bounds__(1024) void tile_prefix_kernel(const int *__restrict
         const int item0 = s_carry_item + s_item[tid] - it;
         if (t < n_tiles) {
             tile_base[t] = rec0; item_base[t] = item0;
-            for (int i = 0; i < it; ++i)
-                if (item0 + i < item_capacity) item_tile[item0 + i] = t;
+            for (int i = 0; item_tile && i < it; ++i)
+                if ( item0 + i < item_capacity) item_tile[item0 + i] = t;
         }
         __syncthreads();
         if (tid == 1023) { s_carry_rec += s_rec[1023]; s_carry_item += s_item[1023]; }
@@ -783,51 +785,61 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict
     }
 }
 
-// bins the mid list by tile and builds the work items; sets ta.{geom, w, hband_count (records per tile), hband_base, item_*}
+// bins the mid list by strip and builds the work items; sets ta.{geom, w, hband_count (records per strip), hband_base, item_*}
 template <int NW>
-static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geom, const float *mid_w, long long n_mid, int th, int *n_items_bound,
+static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geom, const float *mid_w, long long n_mid, int th, int *n_items_out,
                            hipStream_t st) {
     Workspace &ws = ctx->ws;
-    const int tiles_x = (ctx->R + 127) / 128, tiles_y = (ctx->R + th - 1) / th, n_tiles = tiles_x * tiles_y;
-    // a footprint below 64 px with one pixel of margin per side spans < 66 px: two 128-px tiles across, three 64-row (four 32-row) down
-    const int max_copies = 2 * (th >= 64 ? 3 : 4);
-    const int64_t need = (int64_t)max_copies * n_mid;
-    if (ws.mband_capacity < need || ws.mtile_capacity < n_tiles) {
-        void *olds[] = {ws.mband_geom, ws.mband_w, ws.mitem_tile, ws.mband_count, ws.mband_base, ws.mitem_base};
+    const int tiles_x = (ctx->R + 63) / 64, tiles_y = (ctx->R + th - 1) / th, n_tiles = tiles_x * tiles_y;
+    if (ws.mtile_capacity < n_tiles) {
+        void *olds[] = {ws.mband_count, ws.mband_base, ws.mitem_base};
         for (void *q : olds)
             if (q) TSP_HIP(hipFree(q));
-        ws.mband_geom = ws.mband_w = nullptr; ws.mitem_tile = ws.mitem_base = ws.mband_count = nullptr; ws.mband_base = nullptr;
-        ws.mband_capacity = std::max<int64_t>(ws.mband_capacity, need + need / 8 + 1024);
-        ws.mtile_capacity = std::max(ws.mtile_capacity, n_tiles);
-        TSP_HIP(hipMalloc(&ws.mband_geom, (size_t)ws.mband_capacity * sizeof(float4)));
-        TSP_HIP(hipMalloc(&ws.mband_w, (size_t)ws.mband_capacity * 2 * sizeof(float)));
-        TSP_HIP(hipMalloc((void **)&ws.mitem_tile, ((size_t)ws.mband_capacity / 64 + ws.mtile_capacity + 1) * sizeof(int)));
+        ws.mband_count = ws.mitem_base = nullptr; ws.mband_base = nullptr;
+        ws.mtile_capacity = n_tiles;
         TSP_HIP(hipMalloc((void **)&ws.mband_count, 2 * (size_t)ws.mtile_capacity * sizeof(int)));               // counts | fill cursors
         TSP_HIP(hipMalloc((void **)&ws.mband_base, ((size_t)ws.mtile_capacity + 1) * sizeof(long long)));
         TSP_HIP(hipMalloc((void **)&ws.mitem_base, ((size_t)ws.mtile_capacity + 1) * sizeof(int)));
     }
-    // records per item: short items balance a short list over the device, long ones amortise a workgroup's LUT load and final flush.
-    // Measured best (one MI355X, 1024^2): 64 records at 3.4e4 mid records, 256 at 3.5e5, 512 at 3.3e6, 2048 at 2.5e7 (512 / 1024 / 2048 /
-    // 4096 there: 14.2 / 13.0 / 12.4 / 13.3 ms) -- about 0.35 sqrt(n), rounded to a power of two
+    // records per item: short items balance a short list over the device, long ones amortise the LUT load and the final flush
     int item_records = ctx->mid_item_records;
     if (item_records <= 0) {
-        const double want = 0.35 * std::sqrt((double)n_mid);
+        const double want = ctx->mid_item_scale * std::sqrt((double)n_mid);
         item_records = 64;
         while (item_records < GCHUNK_MAX && (double)item_records * 1.41 < want) item_records *= 2;
     }
-    const int item_capacity = (int)std::min<int64_t>(need / item_records + n_tiles, ws.mband_capacity / 64 + ws.mtile_capacity);
     TSP_HIP(hipMemsetAsync(ws.mband_count, 0, 2 * (size_t)ws.mtile_capacity * sizeof(int), st));
     const bool lds = n_tiles <= G_LDS_TILES;
     const unsigned grid = (unsigned)((n_mid + 1023) / 1024);
     hipLaunchKernelGGL(tile_count_kernel, dim3(grid), dim3(256), lds ? n_tiles * sizeof(int) : 0, st, mid_geom, n_mid, ctx->R, th, tiles_x, tiles_y, ws.mband_count);
-    hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int *)ws.mband_count, n_tiles, ws.mband_base, ws.mitem_base, ws.mitem_tile, item_capacity, item_records);
+    // the sizes of the bins are known on the device only: the prefix pass runs once without the item table to size it, the
+    // host reads the two totals (one small copy; the pipeline already synchronises once per frame for the record counts) and grows
+    // the bins when needed, then the pass runs again and writes the table
+    hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int *)ws.mband_count, n_tiles, ws.mband_base, ws.mitem_base, (int *)nullptr, 0, item_records);
+    long long total_records = 0; int total_items = 0;
+    TSP_HIP(hipMemcpyAsync(&total_records, ws.mband_base + n_tiles, sizeof(long long), hipMemcpyDeviceToHost, st));
+    TSP_HIP(hipMemcpyAsync(&total_items, ws.mitem_base + n_tiles, sizeof(int), hipMemcpyDeviceToHost, st));
+    TSP_HIP(hipStreamSynchronize(st));
+    if (ws.mband_capacity < total_records || ws.mitem_capacity < total_items) {
+        void *olds[] = {ws.mband_geom, ws.mband_w, ws.mitem_tile};
+        for (void *q : olds)
+            if (q) TSP_HIP(hipFree(q));
+        ws.mband_geom = ws.mband_w = nullptr; ws.mitem_tile = nullptr;
+        ws.mband_capacity = std::max<int64_t>(ws.mband_capacity, total_records + total_records / 4 + 1024);
+        ws.mitem_capacity = std::max<int64_t>(ws.mitem_capacity, (int64_t)total_items + total_items / 4 + 1024);
+        TSP_HIP(hipMalloc(&ws.mband_geom, (size_t)ws.mband_capacity * sizeof(float4)));
+        TSP_HIP(hipMalloc(&ws.mband_w, (size_t)ws.mband_capacity * 2 * sizeof(float)));
+        TSP_HIP(hipMalloc((void **)&ws.mitem_tile, (size_t)ws.mitem_capacity * sizeof(int)));
+    }
+    hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int *)ws.mband_count, n_tiles, ws.mband_base, ws.mitem_base, ws.mitem_tile, total_items, item_records);
     hipLaunchKernelGGL((tile_fill_kernel<NW>), dim3(grid), dim3(256), lds ? 2 * n_tiles * sizeof(int) : 0, st, mid_geom, mid_w, n_mid, ctx->R, th, tiles_x, tiles_y,
                        (float4 *)ws.mband_geom, (float *)ws.mband_w, (const long long *)ws.mband_base, ws.mband_count + ws.mtile_capacity);
     TSP_HIP(hipGetLastError());
     ta.geom = (const float4 *)ws.mband_geom; ta.w = (const float *)ws.mband_w;
     ta.hband_count = ws.mband_count; ta.hband_stride = 0; ta.hband_base = ws.mband_base;
     ta.item_tile = ws.mitem_tile; ta.item_base = ws.mitem_base; ta.n_tiles = n_tiles; ta.item_records = item_records;
-    *n_items_bound = item_capacity;
+    ta.tiles_x = tiles_x;
+    *n_items_out = total_items;
     return TSP_OK;
 }
 
@@ -835,11 +847,11 @@ template <int MODE, int NACC, int HR, int OCC>
 static int launch_mid_gather_kernel(tsp_context *ctx, TileArgs ta, const float4 *mid_geom, const float *mid_w, long long n_mid, hipStream_t st) {
     const bool quad = ctx->lut_mirror_symmetric && !ctx->debug_gather_full_lut;
     const size_t smem = (size_t)(quad ? MIPQ_TOTAL : MIP_TOTAL) * sizeof(float) + (H2T / 64) * 64 * sizeof(int);
-    int rc, n_items_bound = 0;
+    int rc, n_items = 0;
     ta.n_records = n_mid;
-    ta.tiles_x = (ctx->R + 127) / 128;
-    if ((rc = bin_mid_records<(MODE == TSP_MODE_RGB) ? 2 : 1>(ctx, ta, mid_geom, mid_w, n_mid, 2 * HR, &n_items_bound, st))) return rc;
-    const dim3 grid(n_items_bound);
+    if ((rc = bin_mid_records<(MODE == TSP_MODE_RGB) ? 2 : 1>(ctx, ta, mid_geom, mid_w, n_mid, HR, &n_items, st))) return rc;
+    if (n_items == 0) return TSP_OK;
+    const dim3 grid((n_items + H2T / 64 - 1) / (H2T / 64));
     if (quad) {
         if (ta.count_frag) hipLaunchKernelGGL((splat_mid_gather_kernel<MODE, NACC, HR, OCC, true, true>), grid, dim3(H2T), smem, st, ta);
         else hipLaunchKernelGGL((splat_mid_gather_kernel<MODE, NACC, HR, OCC, true, false>), grid, dim3(H2T), smem, st, ta);

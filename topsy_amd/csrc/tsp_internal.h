@@ -76,7 +76,8 @@ struct Workspace {     // per-context scratch of the three-class pipeline (grown
     int *mband_count = nullptr;                     // records per tile | fill cursors
     long long *mband_base = nullptr;                // first record of each tile's bin
     int64_t mband_capacity = 0;                     // records the bins can hold
-    int mtile_capacity = 0;                         // tiles the per-tile arrays can hold
+    int mtile_capacity = 0;                         // strips the per-strip arrays can hold
+    int64_t mitem_capacity = 0;                     // work items the item table can hold
     int *mitem_tile = nullptr, *mitem_base = nullptr; // kernel G work items: item -> tile, tile -> first item
     int64_t chunk_capacity = 0;         // chunks alive_list can hold
     float4 *block_bounds = nullptr;     // chunk culling: bounds of every BOUNDS_BLOCK particles (valid while bounds_valid)
@@ -135,6 +136,7 @@ struct tsp_context {
     int reorder_interleave = 2;     // tsp_reorder_spatial's arrangement inside every 512-particle block: 0 Morton order, 1 transposed 64 x 8, 2 by descending smoothing length (tsp_data.hip)
     int stream_blocks_per_cu = 0;    // kernel S: persistent workgroups per CU (0 = what the occupancy query reports)
     int debug_gather_full_lut = 0;   // kernel G: 1 = the whole mip pyramid in LDS even when the kernel image is symmetric (measurement aid)
+    double mid_item_scale = 0.35;    // kernel G: records per work item = this x sqrt(records), rounded to a power of two (option mid_item_scale_milli)
     int mid_item_records = 0;        // kernel G: records per work item (0 = by list length; a power of two from 64 to 1024)
     int stream_batch_chunks = 8;     // kernel S: the largest batch of consecutive chunks a workgroup takes from the shared counter
     bool chunk_cull = true;           // chunks (512 consecutive particles) whose bounds lie outside the view are skipped by kernel S
