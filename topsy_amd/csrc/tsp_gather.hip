@@ -376,6 +376,13 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 // -- two vector instructions and a 4-byte LDS read per 64 pixels, against a multiply, a float64 conversion and a 9-clock ds_add_f64 per
 // 64 pixels (plus their share of the row / column set-up) in the scatter kernel M, whose LDS atomics bound it.
 // Records: the mid list binned by 64-row image band (bin_records), dealt to the `split` workgroups of a tile as in H2.
+// strip height and waves per SIMD of kernel G by accumulator sets (1e9 density: 10.6 ms at 7 waves, 10.0 at 8; 64 x 16 strips 11.2)
+#ifndef TSP_G_OCC1
+#define TSP_G_OCC1 8
+#define TSP_G_HR1 32
+#define TSP_G_OCC2 8
+#define TSP_G_OCC3 5
+#endif
 constexpr int GCHUNK_MAX = 1024;          // records per work item of kernel G (fewer for short lists: enough items to fill the device)
 constexpr int G_LDS_TILES = 8192;         // the binning passes keep their tile counters in LDS up to this many tiles (global atomics beyond)
 
@@ -866,9 +873,9 @@ static int launch_mid_gather_kernel(tsp_context *ctx, TileArgs ta, const float4 
 template <int MODE>
 static int launch_mid_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel, const float4 *mid_geom, const float *mid_w, long long n_mid, hipStream_t st) {
     TSP_REQUIRE(n_mid < (1ll << 28), TSP_EINVAL, "%lld mid footprints in one render block (kernel G indexes its work items with 32 bits)", n_mid);
-    if (MODE == TSP_MODE_RGB) return launch_mid_gather_kernel<MODE, 3, 16, 5>(ctx, ta, mid_geom, mid_w, n_mid, st);
-    if (second_channel) return launch_mid_gather_kernel<MODE, 2, 16, 7>(ctx, ta, mid_geom, mid_w, n_mid, st);
-    return launch_mid_gather_kernel<MODE, 1, 32, 7>(ctx, ta, mid_geom, mid_w, n_mid, st);
+    if (MODE == TSP_MODE_RGB) return launch_mid_gather_kernel<MODE, 3, 16, TSP_G_OCC3>(ctx, ta, mid_geom, mid_w, n_mid, st);
+    if (second_channel) return launch_mid_gather_kernel<MODE, 2, 16, TSP_G_OCC2>(ctx, ta, mid_geom, mid_w, n_mid, st);
+    return launch_mid_gather_kernel<MODE, 1, TSP_G_HR1, TSP_G_OCC1>(ctx, ta, mid_geom, mid_w, n_mid, st);
 }
 
 int launch_mid_gather(tsp_context *ctx, TileArgs ta, int mode, bool second_channel, const float4 *mid_geom, const float *mid_w,
