@@ -72,7 +72,11 @@ const char *tsp_last_error(void);
  * "p_mega_px", "p_mega2_px", "p_mega_rgb_px", "mega_variant", "rgb_mega_variant", "mega_split", "integrated_px" (kernel I, the
  * inexact option of round 3) and "huge_variant" = 0 / 3 now return TSP_EINVAL; tsp_stats keeps its layout (ms_mega, n_mega and
  * n_fragments_mega are reserved: always 0).  New entry points: tsp_set_reduced_image, tsp_group_shard_range,
- * tsp_group_upload_band_magnitudes. */
+ * tsp_group_upload_band_magnitudes.
+ * 105: the LDS scatter kernel of the footprints below 64 px (kernel M) is gone -- kernel G, a register gather over per-strip bins of
+ * the deferred records, draws them at every size: the options "mid_split" and "debug_extra_lds" return TSP_EINVAL; new options
+ * "mid_item_records", "mid_item_scale_milli", "stream_batch_chunks", "debug_gather_full_lut"; "stream_blocks_per_cu" now counts the
+ * persistent workgroups of kernel S per CU (0 = as many as stay resident).  No entry point or struct changed. */
 int tsp_version(void);
 int tsp_stats_size(void);
 
@@ -231,7 +235,7 @@ typedef struct {
     double ms_stream, ms_mid, ms_huge, ms_total; /* per-kernel GPU time, hipEvents; ms_huge = kernel H2 */
     double ms_mega;        /* reserved (0): a second gather kernel existed in rounds 2-4 */
     int64_t n_mega;        /* reserved (0) */
-    /* n_fragments by the kernel that drew them (counted like n_fragments; 0 on the generic pipeline): kernel S, kernel M,
+    /* n_fragments by the kernel that drew them (counted like n_fragments; 0 on the generic pipeline): kernel S, kernel G,
      * kernel H2, reserved (0) -- what bench.py prices each kernel's fragment-rate roofline with */
     int64_t n_fragments_stream, n_fragments_mid, n_fragments_huge, n_fragments_mega;
     /* of n_culled: particles of chunks (512 consecutive particles) whose bounding box lay outside the view -- never read
@@ -241,8 +245,9 @@ typedef struct {
 int tsp_get_stats(tsp_context *ctx, tsp_stats *out);
 /* Options by name.  "count_fragments" (0/1): fragment counting (adds atomics; off by default).  "use_quantity" (0/1): render
  * density-only without dropping the resident quantity.  "chunk_cull" (1/0), "reorder_interleave" (1/0, read by the next
- * tsp_reorder_spatial).  The remaining names are tuning and measurement aids of the pipeline ("p_small_milli", "mid_split",
- * "huge_split", "huge_variant", "stream_blocks_per_cu", "overlap_mid_huge", "debug_*"; csrc/tsp_api.hip). */
+ * tsp_reorder_spatial).  The remaining names are tuning and measurement aids of the pipeline ("p_small_milli", "huge_split",
+ * "huge_variant", "huge_band_mib", "mid_item_records", "mid_item_scale_milli", "stream_blocks_per_cu", "stream_batch_chunks",
+ * "overlap_mid_huge", "debug_*"; csrc/tsp_api.hip). */
 int tsp_set_option(tsp_context *ctx, const char *name, int64_t value);
 
 /* Streaming-read microbenchmark (float4 read-sum over `bytes` of device memory; best of a few launch shapes): returns GB/s.

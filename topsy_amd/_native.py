@@ -16,7 +16,7 @@ MODE_WEIGHTED, MODE_DEPTH, MODE_RGB = 0, 1, 2
 PIPE_DEFAULT, PIPE_GENERIC = 0, 1
 SAMPLE_BILINEAR_MIP0, SAMPLE_BILINEAR_MIP = 0x10, 0x20      # diagnostic sampling rules (generic kernel)
 UNIQUE_ID_BYTES = 128
-ABI_VERSION = 104            # include/topsy_splat.h: tsp_version()
+ABI_VERSION = 105            # include/topsy_splat.h: tsp_version()
 
 
 class BackendUnavailable(RuntimeError):

@@ -104,7 +104,7 @@ using namespace tsp;
 extern "C" {
 
 const char *tsp_last_error(void) { return g_err; }
-int tsp_version(void) { return 104; }     // 101: tsp_stats gained ms_mega, n_mega (16 bytes); 102: the per-kernel fragment counts (32 bytes); 103: n_chunk_culled (8 bytes); 104: matrix-core / kernel-I options removed
+int tsp_version(void) { return 105; }     // 101: tsp_stats gained ms_mega, n_mega (16 bytes); 102: the per-kernel fragment counts (32 bytes); 103: n_chunk_culled (8 bytes); 104: matrix-core / kernel-I options removed; 105: kernel M's options removed (kernel G draws the mid footprints)
 int tsp_stats_size(void) { return (int)sizeof(tsp_stats); }
 
 int tsp_device_count(void) {
