@@ -20,7 +20,7 @@ lines rank 0 also times the whole snapshot on its own GPU afterwards and reports
 Prints ONE JSON line on rank 0 with the contract's keys plus `roofline` (HBM: the frame and kernel S -- the one kernel that
 streams the particles -- first, then every kernel with ITS OWN algorithmic bytes, PMC traffic and traffic / algorithmic;
 durations from hipEvents on the stream the kernels run on), `roofline_fragment` (the frame and every kernel against the f32
-vector peak, priced by the fragments they draw: the bound that decides kernels M and H2) and `cpu_baseline` (the CPU oracle,
+vector peak, priced by the fragments they draw: the bound that decides kernels G and H2) and `cpu_baseline` (the CPU oracle,
 kind "port", on a bounded uniform sample of the same snapshot on the host cores; `pynbody.sph.image` beside it when pynbody
 can be imported).  At N = 1 the line also carries driver-timed extras: `shards_of_1e9_x8` (the 8 REAL index-range shards of
 the snapshot, one after another on this GPU: per-shard frame, max / mean, and the projected 1 -> 8 speed-up), the product
@@ -51,7 +51,7 @@ VALU_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32 vector peak (256 CUs 
 # = 2 FMAs once the x-interpolated texel rows exist; nearest (kernels S / M) one multiply-add of the texel into the pixel
 FMAS_PER_FRAGMENT = {"stream": 1, "mid": 1, "huge": 2}
 B_ALG = {"density": 20, "weighted": 24, "rgb": 28}     # algorithmic bytes/particle
-KERNELS = ("stream", "mid", "huge")        # tsp_stats names of kernels S, M, H2
+KERNELS = ("stream", "mid", "huge")        # tsp_stats names of kernels S, G, H2
 KERNEL_SYMBOL = {"stream": "splat_stream_kernel", "mid": "splat_mid_gather_kernel", "huge": "splat_huge2_kernel"}
 # one ncclReduce of the R^2 x C float32 image onto the root over xGMI (ring: 7 steps of 1/8 of the image per link, ~153 GB/s per
 # link and ~20 us per step): an ESTIMATE -- no multi-GPU box was available to this build -- used only by `projected_speedup_1to8`
@@ -141,7 +141,7 @@ def make_context(_native, mips, R, channels, device, n_total, first, count, args
 
 
 def count_fragments(ctx, M, sf, mode, flags=0):
-    """one extra frame with the fragment counters on: total and per kernel (S, M, H / H2, H3)"""
+    """one extra frame with the fragment counters on: total and per kernel (S, G, H2)"""
     ctx.set_option("count_fragments", 1)
     ctx.render(M, sf, clear=True, mode=mode, flags=flags)
     st = ctx.stats()
@@ -413,7 +413,7 @@ def hbm_roofline(args, means, records, n_per, n_total, world, ms_per_step, R, ch
     FRAME (B_alg bytes per particle over the whole step) and kernel S, the one kernel that streams the particles.  Then every
     kernel with its own algorithmic bytes per launch -- S: particles x B_alg; M, H2: their records x 20 B (24 B rgb) plus one
     float64 flush of the image -- its PMC traffic (profiles/latest_bench_counters.json: 2 x FETCH_SIZE + WRITE_SIZE, as
-    MI355X_MICROARCH.md prescribes for gfx950) and traffic / algorithmic.  Kernels M and H2 are NOT HBM kernels: their bound is
+    MI355X_MICROARCH.md prescribes for gfx950) and traffic / algorithmic.  Kernels G and H2 are NOT HBM kernels: their bound is
     the fragment rate (`roofline_fragment`); their rows are here so that wasted re-reads show."""
     b_alg = B_ALG[args.mode]
     rec_bytes = 24 if args.mode == "rgb" else 20

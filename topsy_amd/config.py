@@ -28,7 +28,7 @@ SPATIAL_ORDER_STRATA = 8
 # large snapshots get more strata so that a stratum -- the smallest spatially unbiased block of the progressive
 # renderer -- holds at most about this many particles: 3.2e7 particles render in ~6 ms on an MI355X, well inside the
 # 1/30 s frame budget.  Fewer, larger strata keep 512-particle chunks more local on screen: the 1e9-particle snapshot in
-# 32 strata renders in 65.8 ms, in 250 (the 4e6-particle strata of rounds 1-4) 67.4 ms (kernel M 16.2 / 17.6 ms); 16 cost
+# 32 strata renders in 65.8 ms, in 250 (the 4e6-particle strata of rounds 1-4) 67.4 ms (the mid-footprint kernel 16.2 / 17.6 ms); 16 cost
 # kernel S 1.2 ms (more same-pixel collisions in its LDS window)
 MAX_PARTICLES_PER_STRATUM = 32_000_000
 SPATIAL_ORDER_MAX_STRATA = 400

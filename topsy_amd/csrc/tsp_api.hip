@@ -201,7 +201,7 @@ int tsp_set_kernel_mips(tsp_context *ctx, const float *lut, int n0, int n_levels
             }
     }
     ctx->lut_zero_outside_disc = zero;
-    // mirror symmetry, bit for bit (kernel M then keeps one quadrant of every level in LDS)
+    // mirror symmetry, bit for bit (kernel G then keeps one quadrant of every level in LDS)
     bool sym = true;
     for (int l = 0, off = 0; l < 4 && sym; off += (64 >> l) * (64 >> l), ++l) {
         const int n = 64 >> l;

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 #undef TSP_H2_GROUP
 #undef TSP_H2_ROW
             if (CNT) n_frag += (unsigned long long)(ncov_x * __popcll((unsigned long long)covmask));
-#ifdef TSP_H2_DEBUG      // analysis build: (footprint, strip) pairs, covered rows and texel-row changes instead of the S / M fragment counts
+#ifdef TSP_H2_DEBUG      // analysis build: (footprint, strip) pairs, covered rows and texel-row changes instead of the S / G fragment counts
             if (CNT && lane == 0) {
                 atomicAdd(&a.cnt->n_frag_class[0], 1ull);
                 atomicAdd(&a.cnt->n_frag_class[1], (unsigned long long)__popcll((unsigned long long)covmask));
@@ -374,8 +374,8 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 // + weight of every pixel column once (one per lane); a covered pixel row then costs
 //       address = row address (DPP operand, quad_perm) + column offset ;  k = LUT[address] (LDS read) ;  acc += k * weight
 // -- two vector instructions and a 4-byte LDS read per 64 pixels, against a multiply, a float64 conversion and a 9-clock ds_add_f64 per
-// 64 pixels (plus their share of the row / column set-up) in the scatter kernel M, whose LDS atomics bound it.
-// Records: the mid list binned by 64-row image band (bin_records), dealt to the `split` workgroups of a tile as in H2.
+// 64 pixels (plus their share of the row / column set-up) in the scatter kernel this one replaced (kernel M, round 5: HISTORY.md), whose LDS atomics bound it.
+// Records: the mid list binned per strip (bin_mid_records below); every wave draws one work item of equal record count.
 // strip height and waves per SIMD of kernel G by accumulator sets (1e9 density: 10.6 ms at 7 waves, 10.0 at 8; 64 x 16 strips 11.2)
 #ifndef TSP_G_OCC1
 #define TSP_G_OCC1 8
@@ -657,11 +657,11 @@ static int bin_huge_records(tsp_context *ctx, TileArgs &ta, const float4 *huge_g
 }
 
 // ---- tile bins of the mid records (kernel G) ----------------------------------------------------------------------
-// Every mid record is copied into the bin of each 128 x TH-pixel tile its square reaches (a footprint below 64 px, one pixel of margin
-// per side: <= 2 tiles across, <= 3 or 4 down; ~2 on average), in three passes -- count, prefix, fill -- so that the bins are exact in
-// size; a workgroup of kernel G then draws one WORK ITEM: item_records consecutive records of one tile's bin.  Items are equal in size and
-// nearly equal in work (every record of a bin reaches the tile), a tile gets as many as its bin needs, and the launch is greedy over
-// ~5e4 of them: binned by image band only, with the same number of workgroups for every tile, the workgroups of the densest
+// Every mid record is copied into the bin of each 64 x HR-pixel strip its square reaches (a footprint below 64 px, one pixel of margin
+// per side: <= 3 strips across, <= 4 or 6 down; ~2.9 on average), in three passes -- count, prefix, fill -- so that the bins are exact in
+// size; a WAVE of kernel G then draws one WORK ITEM: item_records consecutive records of one strip's bin.  Items are equal in size and
+// nearly equal in work (every record of a bin reaches the strip), a strip gets as many as its bin needs, and the launch is greedy over
+// ~7e4 of them: binned by image band only, with the same number of workgroups for every tile, the workgroups of the densest
 // tiles ran ten times longer than the rest and set the kernel's time (1e9 particles: 19.9 / 15.4 / 13.3 ms at 128 / 256 / 512
 // workgroups per tile), and every workgroup scanned the whole band's records for the few that reach its tile.
 

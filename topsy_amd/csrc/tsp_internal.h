@@ -61,7 +61,7 @@ struct Record4 {   // rgb variant (24 B)
 
 struct Counters {      // device-side, zeroed per render call
     unsigned long long n_small, n_mid, n_huge, n_culled, n_fragments, huge_count, next_chunk, pad1;     // next_chunk: kernel S's batch counter
-    unsigned long long n_frag_class[4];   // n_fragments by the kernel that drew them: S, M, H2, (unused)
+    unsigned long long n_frag_class[4];   // n_fragments by the kernel that drew them: S, G, H2, (unused)
 };
 
 struct Workspace {     // per-context scratch of the three-class pipeline (grown on demand)
@@ -142,7 +142,7 @@ struct tsp_context {
     bool chunk_cull = true;           // chunks (512 consecutive particles) whose bounds lie outside the view are skipped by kernel S
                                       // unread: pays with a load-time spatial order (tsp_reorder_spatial); identical results
     int64_t chunk_culled_particles = 0;   // of the last render call
-    bool overlap_mid_huge = false;    // option: kernels M and H on two streams (measured: no gain at 1.25e8, +6 % at 1e7)
+    bool overlap_mid_huge = false;    // option: kernels G and H2 on two streams (measured: no gain at 1.25e8, +6 % at 1e7)
     bool debug_no_raster = false;    // measurement aid: kernel S classifies and emits records but rasterises nothing (the image is then incomplete)
     int cu_count = 256;
     // RCCL

@@ -1,4 +1,4 @@
-// tsp_pipeline.hip -- the splat pipeline (default render path): streaming kernel S, tile-scatter kernel M, host side; gfx950.
+// tsp_pipeline.hip -- the splat pipeline (default render path): streaming kernel S and the host side of a frame; gfx950.
 //
 // What it computes is exactly vertex_* + fragment_* + additive blend of the reference
 // (src/topsy/shaders/sph.wgsl:54-91,139-165; src/topsy/sph.py:31-42) in the canonical arithmetic of
@@ -7,17 +7,14 @@
 // ~1 % of particles wider than 64 px.
 //
 //   kernel S  splat_stream_kernel  streams the SoA particle arrays once (coalesced, 512-particle
-//             chunks, ~10 consecutive chunks per workgroup so load-time spatial order gives screen
-//             locality).  Footprints < p_small px that fit the 64x64-pixel LDS window following the
-//             chunks are rasterised at once (ds_add_f64), flushed with one global atomic per touched
+//             chunks; persistent workgroups take batches of consecutive chunks from a shared counter,
+//             so load-time spatial order gives screen locality and the expensive chunks do not set the
+//             kernel's time).  Footprints < p_small px that fit the LDS window following the chunks
+//             are rasterised at once (ds_add_f64), flushed with one global atomic per touched
 //             pixel.  All other footprints are not rasterised here: their projected records
-//             (pcx, pcy, P, weights) are appended to the MID list (per-chunk contiguous segments with
-//             a pixel bounding box) or the HUGE list (P >= 64 px).
-//   kernel M  splat_mid_kernel     one workgroup per (64x32 image tile, split): walks the segments
-//             whose bbox meets the tile; every lane prepares one record (tile-clipped pixel ranges,
-//             mip level), then each wave rasterises its records one at a time, parameters broadcast
-//             into scalar registers, 8x8 lanes per step, nearest-mip sampling from an LDS copy of the
-//             mip pyramid, ds_add_f64 into the LDS tile (row stride 72: distinct addresses per step).
+//             (pcx, pcy, P, weights) are appended to the MID list or the HUGE list (P >= 64 px).
+//   kernel G  (tsp_gather.hip) draws the MID list (nearest sampling): the records binned per 64-px
+//             pixel strip, equal work items, one per wave, accumulators in registers.
 //   kernel H2 (tsp_gather.hip) takes the footprints >= 64 px (bilinear sampling): per-wave pixel strips held in
 //             registers, records scanned per wave, no atomics in the loop.
 //
@@ -474,7 +471,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
             dy0 = min(dy0, max(iy0 - woy, 0)); dy1 = max(dy1, min(iy1 - woy, WIN - 1));
         }
 
-        // ---- phase 3: a small footprint that does not fit the window joins the MID list (kernel M
+        // ---- phase 3: a small footprint that does not fit the window joins the MID list (kernel G
         //      rasterises any width with the same nearest-mip rule), so phase 4 is LDS-only -----------
 #pragma unroll
         for (int k = 0; k < KPT; ++k) {
@@ -601,7 +598,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
 #pragma unroll
                     for (int j = 0; j < NC; ++j) {
                         const int ci = 6 * g + j;
-#ifdef TSP_S_DEBUG       // analysis build: lane slots the raster loop spends (64 per executed pixel step), reported as the M fragment count
+#ifdef TSP_S_DEBUG       // analysis build: lane slots the raster loop spends (64 per executed pixel step), reported as the mid fragment count
                         if (count_frag && lane == 0) dbg_slots += 64ull;
 #endif
                         double *d = wrow + ci;
@@ -702,8 +699,8 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
 // ---------------------------------------------------------------------------------------------
 // fragment_rgb writes (k r, k g, k b, 1): channel 3 counts the footprint SQUARES covering a pixel, also where
 // the kernel value is exactly 0.  Per footprint that is the indicator of a pixel rectangle, so instead of one add
-// per fragment kernels M and H2 leave the channel alone (H2 may then skip whatever lies outside the kernel's disc,
-// M saves a quarter of its LDS atomics) and the rectangles are summed exactly in integers: +-1 at the four corners of each rectangle, then a 2-D prefix
+// per fragment kernels G and H2 leave the channel alone (they may then skip whatever lies outside the kernel's disc
+// and carry three accumulator sets instead of four) and the rectangles are summed exactly in integers: +-1 at the four corners of each rectangle, then a 2-D prefix
 // sum, added to the float64 render target.
 __global__ __launch_bounds__(256) void rect_count_corners_kernel(const float4 *__restrict__ geom, long long n, int R, int *__restrict__ D) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
