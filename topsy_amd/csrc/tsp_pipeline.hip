@@ -292,19 +292,23 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
     auto flush = [&]() {
         // one global atomic per touched pixel and channel; only the dirty rectangle is visited
         if (dx1 >= dx0) {
+            // a wave per window row, a lane per column (the window is at most 60 pixels wide): no index division (as one linear
+            // index over the rectangle, its quotient and remainder were ~25 of the ~35 instructions per visited pixel)
+            static_assert(WIN <= 64, "one lane per window column");
             double *img = KA()->img;
-            const int fw = dx1 - dx0 + 1, fn = fw * (dy1 - dy0 + 1);
-            for (int idx = tid; idx < fn; idx += SBLOCK) {
-                const int jj = idx / fw;
-                const int wy = dy0 + jj, wx = dx0 + (idx - jj * fw);
-                const int gx = wox + wx, gy = woy + wy;
-                const int o = wy * WIN + wx;
+            const int wx = dx0 + lane;
+            if (wx <= dx1) {
+                const int gx = wox + wx;
+                for (int wy = dy0 + wv; wy <= dy1; wy += SWAVES) {
+                    const int gy = woy + wy;
+                    const int o = __mul24(wy, WIN) + wx;
 #pragma unroll
-                for (int c = 0; c < WC; ++c) {
-                    const double v = win[c * WIN * WIN + o];
-                    if (v != 0.0) {
-                        if (gx < R && gy < R) gatomic_add(img + ((size_t)gy * R + gx) * C + c, v);
-                        win[c * WIN * WIN + o] = 0.0;
+                    for (int c = 0; c < WC; ++c) {
+                        const double v = win[c * WIN * WIN + o];
+                        if (v != 0.0) {
+                            if (gx < R && gy < R) gatomic_add(img + ((size_t)gy * R + gx) * C + c, v);
+                            win[c * WIN * WIN + o] = 0.0;
+                        }
                     }
                 }
             }
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
             const float y0f = (float)jlo + 0.5f;
             const float *lut = T23 + (lvl2 ? 0 : T23_L3);
             const int lstride = lvl2 ? 17 : 9;
-            double *wbase = win + (jlo - woy) * WIN + (ilo - wox);
+            double *wbase = win + __mul24(jlo - woy, WIN) + (ilo - wox);
             if (MODE != TSP_MODE_RGB && WC == 1 && maxnx == 1) {
                 // Every footprint of this wave is one pixel COLUMN wide: the dense core of the snapshot, where thousands of
                 // sub-pixel particles share a pixel and the lanes of a step mostly hit the SAME pixel -- a same-address
