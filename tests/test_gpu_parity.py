@@ -519,11 +519,11 @@ def test_gather_kernel_class_boundaries(native, mips, mode, R):
 
 
 def test_gather_kernels_fold_their_accumulators(native, mips):
-    """More than 512 footprints per wave strip: kernel H2 flushes its float32 accumulators to the float64 target every 512
+    """More than 2048 footprints per wave strip: kernel H2 flushes its float32 accumulators to the float64 target every 2048
     footprints (forced here by one workgroup per tile); density stays within 1e-5 of the oracle for every strip shape /
     occupancy build, the exact fragment count included, whatever the number of workgroups per tile."""
     from oracle import oracle_np
-    R, scale, n = 160, 100.0, 2600
+    R, scale, n = 160, 100.0, 5200
     M, sf = oracle_np.transform_matrix(np.eye(3), np.zeros(3), scale)
     rs = np.random.RandomState(5)
     pos = np.zeros((n, 3), dtype=np.float32)
@@ -624,7 +624,7 @@ def test_asymmetric_kernel_lut_uses_full_tables(native, mips):
 @pytest.mark.parametrize("mode", ["density", "weighted", "rgb", "depth"])
 def test_mid_footprints_gather(native, mips, mode):
     """The footprints below 64 px that kernel S defers are drawn by kernel G (register gather over tile bins of the records):
-    against the oracle, exact fragment count included, for every work-item size, with more than 512 footprints per wave strip
+    against the oracle, exact fragment count included, for every work-item size, with more than 2048 footprints per wave strip
     (float32 accumulators folded into the float64 target), R = 300 (partial last tiles) and widths on the class boundaries and
     on every mip-level threshold."""
     from oracle import oracle_np
@@ -633,7 +633,7 @@ def test_mid_footprints_gather(native, mips, mode):
     rs = np.random.RandomState(23)
     pos = np.zeros((n, 3), dtype=np.float32)
     pos[:, :2] = rs.uniform(-1.1, 1.1, size=(n, 2)) * scale
-    pos[:2000, :2] = rs.uniform(-0.1, 0.1, size=(2000, 2)) * scale          # a dense patch: > 512 footprints on one strip
+    pos[:6000, :2] = rs.uniform(-0.1, 0.1, size=(6000, 2)) * scale          # a dense patch: > 2048 footprints on one strip
     pos[:, 2] = rs.uniform(-0.5, 0.5, n) * scale
     P = np.exp(rs.uniform(np.log(10.0), np.log(63.9), n))
     P[:48] = [63.999, 32.0, 32.0001, 16.0, 16.0001, 11.3137, 11.32, 15.99] * 6

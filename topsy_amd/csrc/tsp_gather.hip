@@ -94,9 +94,11 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     const int myrow = lane & (HR - 1);
     const float pyc_own = (sy + myrow < R) ? (float)(sy + myrow) + 0.5f : __builtin_inff();
 
-    // float32 accumulators hold at most FOLD_EVERY footprints (rounding error ~ sqrt(n) * 2^-24 relative: < 2e-6 at
-    // the worst pixel), then go to the float64 render target; second-level register totals would
-    // cost HR * W more VGPRs and spill here
+    // float32 accumulators hold at most FOLD_EVERY (2048) footprints, then go to the float64 render target: a sum of n non-negative
+    // terms accumulates ~sqrt(n) 2^-24 of relative rounding error at the worst pixel; measured on a 4e7-particle sample of the 1e9
+    // snapshot the image's largest relative error is 2.9e-7 / 3.1e-7 / 3.3e-7 at 512 / 1024 / 2048 (it is the final float32 rounding
+    // that shows), while the float64 flush atomics were 2/3 of the rgb render's HBM writes at 512.  Second-level register totals
+    // would cost HR * W more VGPRs and spill here
     constexpr int FOLD_EVERY = TSP_FOLD_EVERY;
     float acc[HR * W][NACC];
 #pragma unroll

@@ -55,7 +55,7 @@ __device__ __forceinline__ void latomic_add(double *addr, float v) {
 }
 
 #ifndef TSP_FOLD_EVERY
-#define TSP_FOLD_EVERY 512     // footprints a float32 accumulator of kernel H2 holds before it goes to the float64 target
+#define TSP_FOLD_EVERY 2048    // footprints a float32 accumulator of kernels G / H2 holds before it goes to the float64 target (512 until the end of round 5)
 #endif
 #ifndef TSP_HDEAL
 #define TSP_HDEAL 16
