@@ -228,11 +228,11 @@ int tsp_content_values(tsp_context *ctx, const int64_t *ranks, int n_ranks, floa
 typedef struct {
     int64_t n_particles;   /* particles visited (sum of range lengths) */
     int64_t n_small;       /* splatted by the streaming kernel */
-    int64_t n_mid;         /* nearest-mip footprints deferred to the tile-scatter kernel */
+    int64_t n_mid;         /* nearest-mip footprints deferred to kernel G (register gather over per-strip bins) */
     int64_t n_huge;        /* bilinear footprints (P >= 64 px) deferred to the tile-gather kernel */
     int64_t n_culled;      /* z-slab / off-screen / non-finite */
     int64_t n_fragments;   /* pixel updates (only counted when TSP_STATS is enabled) */
-    double ms_stream, ms_mid, ms_huge, ms_total; /* per-kernel GPU time, hipEvents; ms_huge = kernel H2 */
+    double ms_stream, ms_mid, ms_huge, ms_total; /* per-kernel GPU time, hipEvents; ms_mid = kernel G + its binning passes; ms_huge = kernel H2 + its band fill */
     double ms_mega;        /* reserved (0): a second gather kernel existed in rounds 2-4 */
     int64_t n_mega;        /* reserved (0) */
     /* n_fragments by the kernel that drew them (counted like n_fragments; 0 on the generic pipeline): kernel S, kernel G,
