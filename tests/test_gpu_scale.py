@@ -457,3 +457,58 @@ def test_vertex_weights_follow_every_upload(native, mips):
             check(native.MODE_WEIGHTED)
             check(native.MODE_RGB)
     ctx.close()
+
+
+def test_stream_batches_and_persistent_workgroups(native, mips):
+    """Kernel S's persistent workgroups take batches of chunks from a shared counter: whatever the batch size and the number of
+    workgroups per CU (options stream_batch_chunks, stream_blocks_per_cu; 1 workgroup per CU = long serial walks over many
+    batches), every chunk is drawn exactly once -- particle and fragment counts identical, density images equal within the
+    path's 1e-5."""
+    n, R = 6_000_000, 512
+    M, sf = camera(200.0)
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.generate_synthetic(n, 0, n, 4242, 0.0, with_quantity=True)
+    ctx.reorder_spatial(8, 4242)
+    ctx.set_option("count_fragments", 1)
+    ctx.render(M, sf)
+    ref = ctx.read_image().astype(np.float64)
+    st0 = ctx.stats()
+    assert st0["n_small"] > 0 and st0["n_mid"] > 0 and st0["n_huge"] > 0
+    for batch, per_cu in ((4, 0), (8, 1), (64, 2), (8, 16), (4096, 0)):
+        ctx.set_option("stream_batch_chunks", batch); ctx.set_option("stream_blocks_per_cu", per_cu)
+        ctx.render(M, sf)
+        st = ctx.stats()
+        for k in ("n_huge", "n_culled", "n_fragments", "n_chunk_culled"):
+            assert st[k] == st0[k], (k, batch, per_cu)
+        # (which small footprints leave the LDS window for the mid list depends on the chunk sequence of a workgroup)
+        assert st["n_small"] + st["n_mid"] == st0["n_small"] + st0["n_mid"], (batch, per_cu)
+        assert rel_close(ctx.read_image()[..., 0].astype(np.float64), ref[..., 0], 1e-5), (batch, per_cu)
+    ctx.close()
+
+
+def test_mid_bins_with_more_strips_than_lds_counters(native, mips):
+    """Kernel G's binning passes count per strip in LDS up to 8192 strips and with global atomics beyond: a 6000^2 image has
+    94 x 188 = 17 672 strips of 64 x 32 pixels.  Against the oracle, exact fragment count included."""
+    from oracle import oracle_c
+    n, R, scale = 4000, 6000, 100.0
+    M, sf = camera(scale)
+    rs = np.random.RandomState(77)
+    pos = np.zeros((n, 3), dtype=np.float32)
+    pos[:, :2] = rs.uniform(-1.05, 1.05, size=(n, 2)) * scale
+    P = np.exp(rs.uniform(np.log(8.0), np.log(63.9), n))
+    h = (P * scale / (2.0 * R)).astype(np.float32)
+    m = rs.uniform(0.5, 2.0, n).astype(np.float32)
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+    ctx.set_option("count_fragments", 1)
+    ctx.set_option("p_small_milli", 0)
+    ctx.render(M, sf)
+    got = ctx.read_image()[..., 0]
+    st = ctx.stats()
+    assert st["n_mid"] > 3000 and st["n_small"] == 0
+    want, nfrag = oracle_c.splat(pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), h, m, None, None, mode=0, M=M, sf=sf, R=R, mips=mips)
+    assert st["n_fragments"] == nfrag
+    assert np.allclose(got, want[..., 0], rtol=1e-5, atol=0)
+    ctx.close()
