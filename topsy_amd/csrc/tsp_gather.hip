@@ -493,7 +493,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mid_gather_kernel(TileArgs a) 
             unsigned covmask;
             {
                 const float d = pyc_own - pcy;
-                int ty = nearest_index((d + half) * invP, n);
+                int ty = floor_clamp_s(((d + half) * invP) * (float)n, n - 1);      // = nearest_index((d + half) * invP, n), tsp_math.h
                 if (QUAD) ty = min(ty, n - 1 - ty);
                 asm volatile("" ::: "memory");          // (in-order LDS: the previous footprint's table reads are done)
                 rt[lane] = tbase + (ty << (tshift + 2));
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mid_gather_kernel(TileArgs a) 
             {
                 const float d = pxc - pcx;
                 const bool covered = __builtin_fabsf(d) < half;
-                int tx = nearest_index((d + half) * invP, n);
+                int tx = floor_clamp_s(((d + half) * invP) * (float)n, n - 1);
                 if (QUAD) tx = min(tx, n - 1 - tx);
                 tx4 = tx * 4;
 #pragma unroll

@@ -85,6 +85,19 @@ __device__ __forceinline__ int nearest_index(float u, int n) {
     return clampi((int)__builtin_floorf(u * (float)n), 0, n - 1);
 }
 
+// clampi((int)floorf(x), 0, hi) in two instructions instead of four: v_cvt_flr_i32_f32 converts with floor rounding (and saturates
+// like the plain conversion), v_med3_i32 clamps.  The same integers for every x; `hi` wave-uniform (_s) or per lane (_v).
+__device__ __forceinline__ int floor_clamp_s(float x, int hi) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1\n\tv_med3_i32 %0, %0, 0, %2" : "=&v"(r) : "v"(x), "s"(hi));
+    return r;
+}
+__device__ __forceinline__ int floor_clamp_v(float x, int hi) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1\n\tv_med3_i32 %0, %0, 0, %2" : "=&v"(r) : "v"(x), "v"(hi));
+    return r;
+}
+
 __device__ __forceinline__ int mip_offset(int lvl) {  // 0, 4096, 5120, 5376
     return lvl == 0 ? 0 : (lvl == 1 ? 4096 : (lvl == 2 ? 5120 : 5376));
 }

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                 if (__ballot(ci < nx) == 0ull) break;
                 maxnx = ci + 1;
                 const float dx = (x0f + (float)ci) - pcx[k];
-                const int tx = clampi((int)__builtin_floorf(((dx + half) * ip) * nf), 0, nm1);
+                const int tx = floor_clamp_v(((dx + half) * ip) * nf, nm1);
                 pk[ci / 6] ^= ((ci < nx) ? ((unsigned)tx ^ zc) : 0u) << (5 * (ci % 6));
             }
             const float y0f = (float)jlo + 0.5f;
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                 // across the wave first (DPP tree) and one lane issues the one atomic.
                 if (__ballot(act && ny != 1) == 0ull) {
                     const float dy = y0f - pcy[k];
-                    const int ty = clampi((int)__builtin_floorf(((dy + half) * ip) * nf), 0, nm1);
+                    const int ty = floor_clamp_v(((dy + half) * ip) * nf, nm1);
                     const float kv = act ? lut[__mul24(ty, lstride) + (int)(pk[0] & 31u)] : 0.0f;
                     const float val = kv * w0[k];
                     const int key = (int)(wbase - win);
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(SBLOCK, TSP_S_OCC) void splat_stream_kernel(StreamA
                 const bool rowact = r < ny;
                 if (__ballot(rowact) == 0ull) break;
                 const float dy = (y0f + (float)r) - pcy[k];
-                const int ty = clampi((int)__builtin_floorf(((dy + half) * ip) * nf), 0, nm1);
+                const int ty = floor_clamp_v(((dy + half) * ip) * nf, nm1);
                 const float *lrow = lut + __mul24(rowact ? ty : (int)zc, lstride);      // (24-bit multiply: full rate; v_mul_lo_u32 runs at a quarter)
                 double *wrow = wbase + r * WIN;
                 // a group = six footprint columns (one register of texel fields); its pixel steps are unrolled for 2, 4 or 6
