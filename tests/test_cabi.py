@@ -64,3 +64,18 @@ def test_missing_library_fails_loudly(tmp_path):
             % (ROOT, str(tmp_path / "libmissing.so")))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert "UNAVAILABLE" in out.stdout and "libmissing.so" in out.stdout, out.stdout + out.stderr
+
+
+def test_every_option_name_is_documented():
+    """INTEGRATION.md section 6 lists every name tsp_set_option accepts (csrc/tsp_api.hip), and names no option that is gone."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    api = open(os.path.join(root, "topsy_amd", "csrc", "tsp_api.hip")).read()
+    body = api[api.index("int tsp_set_option("):]
+    body = body[:body.index('set_error("unknown option')]
+    accepted = set(re.findall(r'!strcmp\(name, "([a-z_0-9]+)"\)', body))
+    assert {"count_fragments", "chunk_cull", "mid_item_records", "stream_batch_chunks", "huge_split"} <= accepted
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    table = doc[doc.index("## 6. Tuning knobs"):]
+    documented = set(re.findall(r"`([a-z_0-9]+)`", "\n".join(l.split("|")[1] for l in table.splitlines() if l.startswith("| `"))))
+    assert accepted == documented, (sorted(accepted - documented), sorted(documented - accepted))
