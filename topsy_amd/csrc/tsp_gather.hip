@@ -658,14 +658,15 @@ static int bin_huge_records(tsp_context *ctx, TileArgs &ta, const float4 *huge_g
     return TSP_OK;
 }
 
-// ---- tile bins of the mid records (kernel G) ----------------------------------------------------------------------
+// ---- strip bins of the mid records (kernel G; "tile" in the names below = one 64 x HR strip) --------------------------
 // Every mid record is copied into the bin of each 64 x HR-pixel strip its square reaches (a footprint below 64 px, one pixel of margin
 // per side: <= 3 strips across, <= 4 or 6 down; ~2.9 on average), in three passes -- count, prefix, fill -- so that the bins are exact in
 // size; a WAVE of kernel G then draws one WORK ITEM: item_records consecutive records of one strip's bin.  Items are equal in size and
 // nearly equal in work (every record of a bin reaches the strip), a strip gets as many as its bin needs, and the launch is greedy over
 // ~7e4 of them: binned by image band only, with the same number of workgroups for every tile, the workgroups of the densest
 // tiles ran ten times longer than the rest and set the kernel's time (1e9 particles: 19.9 / 15.4 / 13.3 ms at 128 / 256 / 512
-// workgroups per tile), and every workgroup scanned the whole band's records for the few that reach its tile.
+// workgroups per tile), and every workgroup scanned the whole band's records for the few that reach its tile; bins per 128 x 64 tile
+// with one item per workgroup: 12.35 ms (the four strips of a tile differ in work); per strip with one item per wave: 10.0.
 
 struct TileSpan { int x0, x1, y0, y1; };
 __device__ __forceinline__ TileSpan tile_span(const float4 g, int R, int th, int tiles_x, int tiles_y) {
