@@ -325,7 +325,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload_name, "total_particles": n_total,
                    "particles_per_gpu": n_per, "resolution": R, "sharding": f"index-range x{world}",
-                   "pipeline": "generic" if args.generic else "three-class (stream / mid scatter / row-uniform gather)",
+                   "pipeline": "generic" if args.generic else "three-class (stream S / strip-binned gather G / row-uniform gather H2)",
                    "fragments_per_particle": frags / n_total, "frames_per_s": 1e3 / ms_per_step},
         "ms_per_step_median": ms_median, "value_at_median": n_total / (ms_median * 1e-3),
         "fragments_per_s": frags / (ms_per_step * 1e-3),
