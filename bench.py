@@ -98,6 +98,16 @@ def camera(scale):
     return M, np.float32(1.0 / scale)
 
 
+def camera_b(scale, x_angle=0.0, y_angle=0.4):
+    """camera B (reference tests/test_render_output.py:161-198: `vis.scale = 20; vis.rotate(0, 0.4)`): the
+    Visualizer's own rotation (visualizer.py:347-357) and transform (sph.py:268-289) at the given scale"""
+    cx, sx, cy, sy = np.cos(x_angle), np.sin(x_angle), np.cos(y_angle), np.sin(y_angle)
+    rot = np.array([[cx, 0, sx], [0, 1, 0], [-sx, 0, cx]]) @ np.array([[1, 0, 0], [0, cy, -sy], [0, sy, cy]])
+    to_clip = np.diag([1.0, 1.0, 0.5, 1.0]); to_clip[2, 3] = 0.5
+    rs = np.zeros((4, 4)); rs[:3, :3] = rot / scale; rs[3, 3] = 1.0
+    return (to_clip @ rs).astype(np.float32), np.float32(1.0 / scale)
+
+
 def num_strata(n):
     from topsy_amd.particle_buffers import ParticleBuffers
     return ParticleBuffers._num_strata(n)
@@ -301,7 +311,9 @@ def main():
         return
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = n_total / (elapsed / args.steps)
+    shard_only = bool(args.as_shard) and world == 1        # only n_per particles are resident and drawn: every rate counts those
+    n_drawn = n_per if shard_only else n_total
+    value = n_drawn / (elapsed / args.steps)
     ms_median = float(np.median(step_s)) * 1e3
     config_tag = " = BASELINE.json configs[3]" if (n_total == 10**9 and args.mode == "density" and R == 1024 and not weak
                                                     and args.h_cap_px <= 0) else ""
@@ -326,18 +338,18 @@ def main():
         "config": {"workload": workload_name, "total_particles": n_total,
                    "particles_per_gpu": n_per, "resolution": R, "sharding": f"index-range x{world}",
                    "pipeline": "generic" if args.generic else "three-class (stream S / strip-binned gather G / row-uniform gather H2)",
-                   "fragments_per_particle": frags / n_total, "frames_per_s": 1e3 / ms_per_step},
-        "ms_per_step_median": ms_median, "value_at_median": n_total / (ms_median * 1e-3),
+                   "fragments_per_particle": frags / n_drawn, "frames_per_s": 1e3 / ms_per_step},
+        "ms_per_step_median": ms_median, "value_at_median": n_drawn / (ms_median * 1e-3),
         "fragments_per_s": frags / (ms_per_step * 1e-3),
-        "roofline": hbm_roofline(args, means, records, n_per, n_total, world, ms_per_step, R, channels, prof, measured_peak),
+        "roofline": hbm_roofline(args, means, records, n_per, n_drawn, world, ms_per_step, R, channels, prof, measured_peak),
         # per GPU: a rank draws 1/N of the frame's fragments (rank 0's kernel times beside the mean share)
         "roofline_fragment": fragment_roofline({k: v / world for k, v in frags_by_kernel.items()}, means, ms_per_step),
         "kernel_ms": means,
         "setup_s": t_setup,
     }
     if args.as_shard and world == 1:
-        result["as_shard"] = (f"only the index range [{first}, {first + n_per}) of the snapshot is resident and rendered (shard {args.as_shard}): "
-                              "`value` counts the whole snapshot's particles and is NOT a measurement of it")
+        result["as_shard"] = (f"only the index range [{first}, {first + n_per}) of the {n_total:.4g}-particle snapshot is resident and rendered "
+                              f"(shard {args.as_shard}): `value`, the roofline and the per-particle figures count these {n_per} particles")
     if args.shared_device_dry_run:
         result["dry_run"] = ("ranks shared device 0 and the shard images were summed on the host instead of by RCCL: harness test "
                              "only, `value` is not a measurement")
@@ -367,6 +379,10 @@ def main():
     extras = world == 1 and not args.generic and not args.headline_only and args.h_cap_px <= 0 and not args.as_shard
     if extras and args.mode == "density":
         whole_ms = ms_per_step
+        # fragment-heavy cameras (SURVEY section 8d camera B) on the headline snapshot while it is resident, and on 1e8 below
+        result["zoomed_frame"] = {"workload": f"one whole-snapshot tsp_render, density, {R}^2, camera B of SURVEY section 8d "
+                                              "(tests/test_render_output.py:161-198) and the same rotation at scale 50",
+                                  f"{n_total:.4g}": zoomed_lines(ctx, n_total, R, mode)}
         if ctx is not None:
             ctx.close()
         if n_total == 10**9 and R == 1024 and not weak:
@@ -386,6 +402,7 @@ def main():
                                                   "BASELINE.json configs[1]: 1e7 particles, density-weighted quantity")
         result["baseline_config_2"] = config_line(ctx, 100_000_000, "density", R, args,
                                                   "BASELINE.json configs[2]: exactly 1e8 dm particles, density")
+        result["zoomed_frame"]["1e+08"] = zoomed_lines(ctx, 100_000_000, R, mode)
         ctx.close()
         ctx = None
         c5 = _native.Context(2048, 4, device_id=local_rank)
@@ -396,6 +413,7 @@ def main():
         # the product path: the same frames through the Visualizer / SPH / ColormapHolder surface (reference visualizer.py, sph.py:306-332)
         result["visualizer_export_frame"] = visualizer_lines(local_rank, R, args, whole_ms, n_total if (n_total == 10**9 and not weak) else None)
         result["interactive_frame"] = interactive_line(local_rank, R, args)
+        result["interactive_frame_zoomed"] = interactive_line(local_rank, R, args, zoom=20.0)
     if not args.no_cpu_baseline and not args.headline_only and world == 1 and not args.as_shard:      # reported baseline: rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(args, n_total, M, sf, R)
     print(json.dumps(result), flush=True)
@@ -437,16 +455,24 @@ def hbm_roofline(args, means, records, n_per, n_total, world, ms_per_step, R, ch
     s_gbps = alg["stream"] / (s_ms * 1e-3) / 1e9 if s_ms > 0 else 0.0
     frame_gbps = b_alg * n_total / (ms_per_step * 1e-3) / 1e9 / world
     by_time = max(("stream", "mid", "huge"), key=lambda k: means.get(k, 0.0))
-    return {"bound": "hbm", "kernel": KERNEL_SYMBOL["stream"], "achieved": s_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": s_gbps / HBM_PEAK_GBPS, "traffic": per["stream"]["traffic"], "traffic_unit": "GB per launch (PMC)",
-            "kernel_ms": s_ms, "algorithmic_bytes_per_launch": alg["stream"],
-            "frame": {"achieved": frame_gbps, "frac": frame_gbps / HBM_PEAK_GBPS, "ms": ms_per_step,
-                      "algorithmic_bytes_per_gpu": b_alg * n_per, "north_star_target_frac": 0.40},
+    traffic_known = [per[k]["traffic"] for k in ("stream", "mid", "huge") if per[k]["traffic"] is not None]
+    frame_traffic = float(sum(traffic_known)) if len(traffic_known) == 3 else None
+    source = None
+    if prof is not None:
+        source = (f"profiles/{prof.get('tag', 'latest')}_bench_counters.json = profiles/latest_bench_counters.json (committed rocprofv3 --pmc passes of this "
+                  "workload, tools/profile_bench.sh), NOT measured in this run")
+    # Top level = the FRAME against the HBM roof, SURVEY section 8d's definition (N x B_alg / step time): the figure the north
+    # star's 40 % is about.  Kernel S -- the one kernel that streams the particles -- and every kernel's own row sit beneath it.
+    return {"bound": "hbm", "kernel": "frame", "achieved": frame_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": frame_gbps / HBM_PEAK_GBPS, "traffic": frame_traffic, "traffic_unit": "GB per frame: the three splat kernels' PMC traffic summed",
+            "traffic_source": source, "ms": ms_per_step, "algorithmic_bytes_per_gpu": b_alg * n_per, "north_star_target_frac": 0.40,
+            "stream_kernel": {"kernel": KERNEL_SYMBOL["stream"], "achieved": s_gbps, "frac": s_gbps / HBM_PEAK_GBPS, "kernel_ms": s_ms,
+                              "algorithmic_bytes_per_launch": alg["stream"], "traffic": per["stream"]["traffic"],
+                              "frac_of_measured_read_peak": s_gbps / measured_peak if measured_peak else None},
             "per_kernel": per, "longest_kernel": KERNEL_SYMBOL[by_time],
             "measured_read_peak_GBps": measured_peak, "guide_measured_copy_GBps": HBM_MEASURED_COPY_GBPS,
-            "frac_of_measured_read_peak": s_gbps / measured_peak if measured_peak else None,
-            "note": "kernel S is the path's HBM-shaped kernel (it streams every particle once); the longest kernel is bound by the "
-                    "fragments it draws, not by bytes -- see roofline_fragment.per_kernel"}
+            "note": "the frame is bound by the fragments it draws (roofline_fragment), not by bytes: kernel S is the path's one HBM-shaped "
+                    "kernel (it streams every particle once), the longest kernel draws records, not particles"}
 
 
 # ---- N > 1: self-validation of the one collective of the path ---------------------------------------------------------
@@ -628,7 +654,7 @@ def visualizer_lines(device, R, args, whole_ms, n_big=None, frames=5):
                         f"protocol, density, {R}^2, camera A, beside tsp_render + tsp_colormap_scalar on the same context", "sizes": out}
 
 
-def interactive_line(device, R, args, n=1_000_000_000, frames=24):
+def interactive_line(device, R, args, n=1_000_000_000, frames=24, zoom=None):
     """The regime the reference is built around (config.py:6-7: 30 frames/s, progressive blocks): Visualizer.draw(CHANGE) on the
     1e9-particle snapshot -- one time-budgeted block + colormap per frame -- until the adaptive block size has settled: how many
     particles a 1/30 s frame draws, and how long the frame really takes."""
@@ -636,6 +662,9 @@ def interactive_line(device, R, args, n=1_000_000_000, frames=24):
     from topsy_amd import DrawReason, config
     try:
         vis = topsy_amd.synthetic_on_device(n, render_resolution=R, device_id=device)
+        if zoom is not None:          # camera B (reference tests/test_render_output.py:161-198)
+            vis.scale = zoom
+            vis.rotate(0.0, 0.4)
         drawn, ms = [], []
         for i in range(frames):
             t = time.perf_counter()
@@ -651,12 +680,15 @@ def interactive_line(device, R, args, n=1_000_000_000, frames=24):
         refine_ms = (time.perf_counter() - t) * 1e3
         vis.close()
         tail = slice(frames // 2, None)
-        return {"workload": f"Visualizer.draw(CHANGE) on the {n:.4g}-particle snapshot, {R}^2, camera A: one progressive block of "
+        cam_name = "camera A" if zoom is None else f"camera B (scale {zoom:g}, rotate(0, 0.4))"
+        return {"workload": f"Visualizer.draw(CHANGE) on the {n:.4g}-particle snapshot, {R}^2, {cam_name}: one progressive block of "
                             f"the 1/{config.TARGET_FPS} s budget + colormap per frame (progressive_render.py:48-86)",
                 "particles_per_frame": float(np.median(drawn[tail])), "ms_per_frame": float(np.median(ms[tail])),
                 "frames_per_s": 1e3 / float(np.median(ms[tail])), "target_frames_per_s": config.TARGET_FPS,
                 "fraction_of_snapshot_per_frame": float(np.median(drawn[tail])) / n,
                 "first_frame_particles": drawn[0], "first_frame_ms": ms[0],
+                "slowest_frame_ms": float(np.max(ms[1:])), "frames_over_budget": int(np.sum(np.asarray(ms[1:]) > 1e3 / config.TARGET_FPS)),
+                "frames_timed": frames - 1, "smallest_block_particles": float(np.min(drawn)),
                 "refine_frames_to_complete": refine, "refine_ms_to_complete": refine_ms}
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"[:240]}
@@ -717,6 +749,34 @@ def config_line(ctx, n, mode_name, R, args, label, frames=10, regenerate=True):
             "fragments_per_s": frags / (med * 1e-3), "frac_of_f32_peak": rf["frac"],
             "kernel_frac_of_f32_peak": {k: v["frac"] for k, v in rf["per_kernel"].items()},
             "frame_GBps": B_ALG[mode_name] * n / (med * 1e-3) / 1e9, "kernel_ms": kms}
+
+
+def zoomed_lines(ctx, n, R, mode, frames=4):
+    """Fragment-heavy cameras on a resident snapshot (SURVEY section 8d camera B: scale 20, rotate(0, 0.4); and the same rotation
+    at scale 50): per-kernel times, record counts and fragments per particle of one whole-snapshot tsp_render."""
+    out = []
+    for scale in (20.0, 50.0):
+        try:
+            M, sf = camera_b(scale)
+            ms, per = [], {k: [] for k in KERNELS}
+            for i in range(frames + 1):
+                t = ctx.render(M, sf, clear=True, mode=mode)
+                if i:
+                    ms.append(t)
+                    st = ctx.stats()
+                    for k in KERNELS:
+                        per[k].append(st["ms_" + k])
+            frags, by_kernel = count_fragments(ctx, M, sf, mode)
+            st = ctx.stats()
+            med = float(np.median(ms))
+            out.append({"camera": f"B: scale {scale:g}, rotate(0, 0.4)", "particles": n, "ms_per_step": med, "frames_per_s": 1e3 / med,
+                        "value": n / (med * 1e-3), "unit": "particles/s", "kernel_ms": {k: float(np.median(v)) for k, v in per.items()},
+                        "records": {k: int(st["n_" + k]) for k in ("small", "mid", "huge", "culled")},
+                        "fragments_per_particle": frags / n, "fragments_per_s": frags / (med * 1e-3),
+                        "fragments_by_kernel": {k: int(v) for k, v in by_kernel.items()}})
+        except Exception as e:       # (never lose the bench line to an extra)
+            out.append({"camera": f"B: scale {scale:g}, rotate(0, 0.4)", "particles": n, "error": f"{type(e).__name__}: {e}"[:240]})
+    return out
 
 
 def cpu_baseline(args, n_total, M, sf, R):

@@ -163,7 +163,9 @@ int64_t tsp_num_particles(tsp_context *ctx);
  *   clear         1 = clear the target first (load_op clear, sph.py:346)
  *   mode          TSP_MODE_*
  *   flags         TSP_PIPE_*
- *   gpu_ms_out    optional: GPU time of this block (hipEvent pair) -- the TimeGpuOperation hook */
+ *   gpu_ms_out    optional: GPU time of this block (hipEvent pair) -- the TimeGpuOperation hook
+ * A block of any size draws (the deferred-footprint lists go through the tile kernels in slices), and it draws whole or not at
+ * all: on any error return the accumulator, the image, the channel layout and tsp_stats are as the call found them. */
 int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64_t *starts,
                const int64_t *lens, int n_ranges, int clear, int mode, int flags, double *gpu_ms_out);
 
@@ -247,7 +249,7 @@ int tsp_get_stats(tsp_context *ctx, tsp_stats *out);
  * density-only without dropping the resident quantity.  "chunk_cull" (1/0), "reorder_interleave" (1/0, read by the next
  * tsp_reorder_spatial).  The remaining names are tuning and measurement aids of the pipeline ("p_small_milli", "huge_split",
  * "huge_variant", "huge_band_mib", "mid_item_records", "mid_item_scale_milli", "stream_blocks_per_cu", "stream_batch_chunks",
- * "overlap_mid_huge", "debug_*"; csrc/tsp_api.hip). */
+ * "overlap_mid_huge", "slice_records", "debug_*"; csrc/tsp_api.hip). */
 int tsp_set_option(tsp_context *ctx, const char *name, int64_t value);
 
 /* Streaming-read microbenchmark (float4 read-sum over `bytes` of device memory; best of a few launch shapes): returns GB/s.

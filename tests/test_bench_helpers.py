@@ -59,14 +59,17 @@ def test_hbm_roofline_prices_every_kernel_with_its_own_bytes():
     prof = {"per_kernel": {"tsp::splat_stream_kernel<0, 1>": {"hbm_read_bytes_corrected": 20.06e9, "hbm_write_bytes": 1.49e9},
                            "tsp::splat_huge2_kernel<0, 1, 1, 32, 8, false>": {"hbm_read_bytes_corrected": 12.73e9, "hbm_write_bytes": 11.08e9}}}
     r = bench.hbm_roofline(A, means, records, 10**9, 10**9, 1, 67.3, 1024, 2, prof, 6660.0)
-    assert r["kernel"] == "splat_stream_kernel" and r["bound"] == "hbm" and r["longest_kernel"] == "splat_huge2_kernel"
-    assert np.isclose(r["achieved"], 20e9 / 17e-3 / 1e9) and np.isclose(r["frac"], r["achieved"] / 8000.0)
-    assert np.isclose(r["frame"]["achieved"], 20e9 / 67.3e-3 / 1e9)
+    # top level = the frame against the HBM roof (N x B_alg / step time); kernel S beneath it
+    assert r["kernel"] == "frame" and r["bound"] == "hbm" and r["longest_kernel"] == "splat_huge2_kernel"
+    assert np.isclose(r["achieved"], 20e9 / 67.3e-3 / 1e9) and np.isclose(r["frac"], r["achieved"] / 8000.0)
+    sk = r["stream_kernel"]
+    assert sk["kernel"] == "splat_stream_kernel" and np.isclose(sk["achieved"], 20e9 / 17e-3 / 1e9) and np.isclose(sk["traffic"], 21.55)
+    assert "NOT measured in this run" in r["traffic_source"]
     h = r["per_kernel"]["huge"]
     assert h["algorithmic_bytes_per_launch"] == 4_232_789 * 20 + 1024 * 1024 * 2 * 8
     assert np.isclose(h["traffic"], 23.81) and h["traffic_over_algorithmic"] > 200
     assert r["per_kernel"]["mid"]["traffic"] is None          # no PMC entry: null, never a guess
-    assert np.isclose(r["traffic"], 21.55)
+    assert r["traffic"] is None                               # the frame's traffic needs all three kernels' entries
 
 
 def test_reduce_selftest_pattern_sums_exactly_and_images_compare():

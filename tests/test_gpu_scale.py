@@ -290,7 +290,8 @@ def test_config5_rgb_2048_full_size(native, mips):
 
 
 def test_config2_weighted_1e7_full_size(native, mips):
-    """BASELINE config 2 at full size: 1e7 particles, density-weighted quantity, 1024^2: pipeline vs generic kernel."""
+    """BASELINE config 2 at full size: 1e7 particles, density-weighted quantity, 1024^2: pipeline vs the library's own GENERIC
+    kernel at this size (the oracle meets the same configuration at full size in test_gpu_baseline_configs.py)."""
     n, R = 10_000_000, 1024
     M, sf = camera(200.0)
     ctx = native.Context(R, 2)
@@ -345,7 +346,7 @@ def test_rgb_2048_matches_oracle_at_class_boundaries(native, mips):
 
 
 @pytest.mark.parametrize("label,h_values", [("wide", (60.0,)), ("two-widths", (20.0, 60.0))])
-def test_record_list_overflow_replay(native, mips, label, h_values):
+def test_huge_list_overflow_replay_weighted_and_rgb(native, mips, label, h_values):
     """An overflow of the huge-record list replays kernel S (records only) after growing the list.  n > 16 * 65536 so the
     first frame must overflow, grow and replay; weighted (NW = 1) and rgb (NW = 2 weights per record)."""
     n, R = 1_100_000, 1024
@@ -511,4 +512,89 @@ def test_mid_bins_with_more_strips_than_lds_counters(native, mips):
     want, nfrag = oracle_c.splat(pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), h, m, None, None, mode=0, M=M, sf=sf, R=R, mips=mips)
     assert st["n_fragments"] == nfrag
     assert np.allclose(got, want[..., 0], rtol=1e-5, atol=0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode_name", ["weighted", "rgb"])
+def test_block_draws_in_record_slices(native, mips, mode_name):
+    """A block of any size draws (sph.py:306-332): the deferred-record lists go through kernels G and H2 in slices (2^27 mid / 2^30
+    huge records by default).  Option slice_records lowers the slice so that 1e6 particles need >= 3 slices of each list; image and
+    fragment counts must equal the oracle's, and the unsliced render's, whatever the slicing."""
+    from oracle import oracle_c
+    n, R = 1_000_000, 512
+    rs = np.random.RandomState(21)
+    pos = (rs.normal(size=(n, 3)) * 60.0).astype(np.float32)
+    # footprints of 2 h R / scale px: a third each below 16 px (kernel S), 16-64 px (kernel G), above 64 px (kernel H2)
+    h = rs.choice(np.asarray([1.0, 2.5, 8.0, 11.0, 14.0, 30.0, 70.0], dtype=np.float32), size=n)
+    m = rs.uniform(0.5, 1.5, n).astype(np.float32)
+    q = rs.uniform(0.1, 1.0, n).astype(np.float32)
+    rgb = rs.uniform(0.0, 1.0, size=(n, 3)).astype(np.float32)
+    M, sf = camera(200.0)
+    rgb_mode = mode_name == "rgb"
+    mode = native.MODE_RGB if rgb_mode else native.MODE_WEIGHTED
+    ctx = native.Context(R, 4 if rgb_mode else 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+    if rgb_mode:
+        ctx.upload_rgb(rgb[:, 0], rgb[:, 1], rgb[:, 2])
+    else:
+        ctx.upload_quantity(q)
+    ctx.set_option("count_fragments", 1)
+    ctx.render(M, sf, mode=mode)
+    whole, st0 = ctx.read_image().astype(np.float64), ctx.stats()
+    n_mid, n_huge = st0["n_mid"], st0["n_huge"]
+    assert n_mid > 200_000 and n_huge > 100_000
+    slice_records = 32768
+    assert n_mid >= 3 * slice_records and n_huge >= 3 * slice_records
+    ctx.set_option("slice_records", slice_records)
+    ctx.render(M, sf, mode=mode)
+    got, st = ctx.read_image().astype(np.float64), ctx.stats()
+    assert (st["n_mid"], st["n_huge"], st["n_fragments"]) == (n_mid, n_huge, st0["n_fragments"])
+    if rgb_mode:
+        want, nfrag = oracle_c.splat(pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), h, rgb[:, 0].copy(), rgb[:, 1].copy(), rgb[:, 2].copy(),
+                                     mode=2, M=M, sf=float(sf), R=R, mips=mips)
+        assert np.array_equal(got[..., 3], want[..., 3]) and np.array_equal(whole[..., 3], want[..., 3])
+        nch = 3
+    else:
+        want, nfrag = oracle_c.splat(pos[:, 0].copy(), pos[:, 1].copy(), pos[:, 2].copy(), h, m, q, mode=0, M=M, sf=float(sf), R=R, mips=mips)
+        nch = 2                      # (q > 0: no cancellation in channel 1)
+    assert st["n_fragments"] == nfrag, "coverage decisions differ from the oracle"
+    for c in range(nch):
+        assert rel_close(got[..., c], want[..., c].astype(np.float64), 1e-5), (mode_name, c)
+        assert rel_close(whole[..., c], want[..., c].astype(np.float64), 1e-5), (mode_name, c)
+    ctx.close()
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_failed_block_leaves_the_accumulator_as_it_found_it(native, mips, stage):
+    """tsp_render draws a block whole or not at all: a failure injected after kernel S (stage 1: its small footprints are already
+    in the accumulator) or after kernel G (stage 2) returns the error and restores the float64 accumulator, the float32 image, the
+    channel layout and the statistics of the previous call -- for a clearing block and for an accumulating one."""
+    n, R = 300_000, 512
+    rs = np.random.RandomState(33)
+    pos = (rs.normal(size=(n, 3)) * 60.0).astype(np.float32)
+    h = rs.choice(np.asarray([1.0, 2.5, 11.0, 30.0], dtype=np.float32), size=n)
+    m = rs.uniform(0.5, 1.5, n).astype(np.float32)
+    M, sf = camera(200.0)
+    M2, sf2 = camera(120.0)
+    half = n // 2
+    ctx = native.Context(R, 2)
+    ctx.set_kernel_mips(mips)
+    ctx.upload_particles(pos[:, 0], pos[:, 1], pos[:, 2], h, m)
+    starts, lens = np.asarray([0], dtype=np.int64), np.asarray([half], dtype=np.int64)
+    ctx.render(M, sf, starts, lens, clear=True)                  # frame A: the first half
+    a, st_a = ctx.read_image().copy(), ctx.stats()
+    for clear, cam in ((True, (M2, sf2)), (False, (M, sf))):
+        ctx.set_option("debug_fail_stage", stage)
+        with pytest.raises(native.BackendError) as err:
+            ctx.render(cam[0], cam[1], np.asarray([half], dtype=np.int64), np.asarray([n - half], dtype=np.int64), clear=clear)
+        assert "injected failure" in str(err.value)
+        assert np.array_equal(ctx.read_image(), a), "the float32 image changed"
+        assert ctx.stats() == st_a, "the statistics changed"
+    # the accumulator itself is intact too: the second half added now gives the whole frame
+    ctx.render(M, sf, np.asarray([half], dtype=np.int64), np.asarray([n - half], dtype=np.int64), clear=False)
+    both = ctx.read_image().astype(np.float64)
+    ctx.render(M, sf)
+    whole = ctx.read_image().astype(np.float64)
+    assert rel_close(both[..., 0], whole[..., 0], 1e-6)
     ctx.close()

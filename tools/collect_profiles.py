@@ -53,7 +53,7 @@ def counters(dirs):
 stats("trace", f"profiles/{tag}_bench_kernel_stats.csv")
 stats("hcap_trace", f"profiles/{tag}_hcapped_kernel_stats.csv")
 stats("shard_trace", f"profiles/{tag}_shard3of8_kernel_stats.csv")
-out = {"command": "python3 bench.py --headline-only under rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum "
+out = {"tag": tag, "command": "python3 bench.py --headline-only under rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum "
                   "TCC_MISS_sum / --pmc SQ_INSTS_* / --pmc SQ_LDS_* SQ_WAIT_* (separate passes); `hcapped` = the same with --particles-per-gpu 1.25e8 "
                   "--h-cap-px 8; `shard3of8` = with --as-shard 8:3 (the index range [3.75e8, 5e8) of the 1e9 snapshot: what one of 8 GPUs renders)",
        "note": "FETCH_SIZE/WRITE_SIZE in KiB per dispatch; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads: "

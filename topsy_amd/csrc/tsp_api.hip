@@ -170,7 +170,7 @@ void tsp_destroy(tsp_context *ctx) {
     (void)hipSetDevice(ctx->device);
     tsp_comm_destroy(ctx);
     free_particles(ctx);
-    void *ptrs[] = {ctx->image, ctx->image64, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->lut2d, ctx->scratch,
+    void *ptrs[] = {ctx->image, ctx->image64, ctx->image64_entry, ctx->mips, ctx->counters, ctx->out8, ctx->outf, ctx->lut, ctx->lut2d, ctx->scratch,
                     ctx->ws.mid_geom, ctx->ws.mid_w, ctx->ws.huge_geom, ctx->ws.huge_w, ctx->ws.hband_geom, ctx->ws.hband_w, ctx->ws.hband_count, ctx->ws.mband_geom, ctx->ws.mband_w, ctx->ws.mband_count, ctx->ws.mband_base, ctx->ws.mitem_tile, ctx->ws.mitem_base, 
                     ctx->ws.block_bounds, ctx->ws.alive_list, ctx->ws.cull_info, ctx->ws.range_prefix, ctx->ws.count_diff, ctx->ws.count_band, ctx->sort_keys, ctx->sort_keys_alt, ctx->sort_tmp};
     for (void *p : ptrs)
@@ -366,8 +366,38 @@ int tsp_download_particles(tsp_context *ctx, float *x, float *y, float *z, float
     return TSP_OK;
 }
 
+static int render_block(tsp_context *ctx, const float *M, float scale_factor, const int64_t *starts, const int64_t *lens,
+                        int n_ranges, int clear, int mode, int flags, double *gpu_ms_out);
+
+// A block draws whole or not at all (the reference's render loop, sph.py:306-332, cannot fail half-way): the float64 accumulator is
+// copied aside on entry (one device-to-device copy of the image: ~10 us at 1024^2) and a block that fails after its first kernel
+// has added to it -- an allocation for its record lists or bins, an injected test failure -- puts accumulator, channel layout and
+// statistics back as the call found them; the float32 presentation image is only written by the last step of a successful block.
 int tsp_render(tsp_context *ctx, const float *M, float scale_factor, const int64_t *starts, const int64_t *lens,
                int n_ranges, int clear, int mode, int flags, double *gpu_ms_out) {
+    TSP_REQUIRE(ctx && M, TSP_EINVAL, "NULL argument");
+    TSP_HIP(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)ctx->R * ctx->R * ctx->Ccap * sizeof(double);
+    if (!ctx->image64_entry) TSP_HIP(hipMalloc((void **)&ctx->image64_entry, bytes));
+    TSP_HIP(hipMemcpyAsync(ctx->image64_entry, ctx->image64, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    const int C_entry = ctx->C;
+    const tsp_stats stats_entry = ctx->stats;
+    const int64_t culled_entry = ctx->chunk_culled_particles;
+    const int rc = render_block(ctx, M, scale_factor, starts, lens, n_ranges, clear, mode, flags, gpu_ms_out);
+    if (rc != TSP_OK) {
+        const std::string why = tsp_last_error();        // (the restore below must not replace the reason of the failure)
+        ctx->C = C_entry; ctx->stats = stats_entry; ctx->chunk_culled_particles = culled_entry;
+        const hipError_t e1 = hipMemcpyAsync(ctx->image64, ctx->image64_entry, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+        const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+        if (e1 != hipSuccess || e2 != hipSuccess) set_error("%s; and the accumulator could not be restored (%s)", why.c_str(), hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        else set_error("%s", why.c_str());
+    }
+    return rc;
+}
+
+static int render_block(tsp_context *ctx, const float *M, float scale_factor, const int64_t *starts, const int64_t *lens,
+                        int n_ranges, int clear, int mode, int flags, double *gpu_ms_out) {
     TSP_REQUIRE(ctx && M, TSP_EINVAL, "NULL argument");
     TSP_REQUIRE(ctx->have_mips, TSP_ESTATE, "tsp_set_kernel_mips must be called before tsp_render");
     TSP_REQUIRE(mode == TSP_MODE_WEIGHTED || mode == TSP_MODE_DEPTH || mode == TSP_MODE_RGB, TSP_EINVAL, "bad mode %d",
@@ -702,6 +732,16 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         TSP_REQUIRE(value >= 0 && value <= 4096, TSP_EINVAL, "%s out of range", name);
         if (name[0] == 'h') ctx->huge_split = (int)value;
         else ctx->stream_blocks_per_cu = (int)value;      // 0 = as many as stay resident
+        return TSP_OK;
+    }
+    if (!strcmp(name, "slice_records")) {     // deferred footprints per launch of kernels G / H2 (0 = default: 2^27 mid, 2^30 huge)
+        TSP_REQUIRE(value == 0 || (value >= 64 && value <= (1ll << 27)), TSP_EINVAL, "%s: 0 or 64 .. 2^27", name);
+        ctx->slice_records = value;
+        return TSP_OK;
+    }
+    if (!strcmp(name, "debug_fail_stage")) {   // test aid: the next tsp_render fails after kernel S (1) or after kernel G (2)
+        TSP_REQUIRE(value >= 0 && value <= 2, TSP_EINVAL, "%s out of range", name);
+        ctx->debug_fail_stage = (int)value;
         return TSP_OK;
     }
     if (!strcmp(name, "debug_gather_full_lut")) { ctx->debug_gather_full_lut = value ? 1 : 0; return TSP_OK; }

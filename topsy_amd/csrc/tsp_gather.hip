@@ -595,7 +595,8 @@ __global__ __launch_bounds__(256) void huge_band_fill_kernel(const float4 *__res
         b0[k] = 1; b1[k] = 0;
         if (first + k < n) {
             g[k] = geom[first + k];
-            const float half = 0.5f * g[k].z, lo = g[k].y - half - 1.0f, hi = g[k].y + half + 1.0f;
+            // (margin: one pixel plus two ulps of the coordinate, so that it still covers the rounding of g.y -+ half beyond 2^23 px)
+            const float half = 0.5f * g[k].z, mg = 1.0f + 2.4e-7f * (__builtin_fabsf(g[k].y) + half), lo = g[k].y - half - mg, hi = g[k].y + half + mg;
             // (non-finite or off-image squares: no band; kernel S emits only records that cover a pixel)
             if (hi >= 0.0f && lo < (float)R && lo == lo && hi == hi) {
                 b0[k] = max(0, (int)__builtin_floorf(fmaxf(lo, 0.0f) * (1.0f / HBAND_H)));
@@ -671,7 +672,9 @@ static int bin_huge_records(tsp_context *ctx, TileArgs &ta, const float4 *huge_g
 struct TileSpan { int x0, x1, y0, y1; };
 __device__ __forceinline__ TileSpan tile_span(const float4 g, int R, int th, int tiles_x, int tiles_y) {
     TileSpan s; s.x0 = s.y0 = 1; s.x1 = s.y1 = 0;
-    const float half = 0.5f * g.z, xl = g.x - half - 1.0f, xh = g.x + half + 1.0f, yl = g.y - half - 1.0f, yh = g.y + half + 1.0f;
+    // (margin: one pixel plus two ulps of the coordinate -- it covers the rounding of g -+ half at any magnitude)
+    const float half = 0.5f * g.z, mx = 1.0f + 2.4e-7f * (__builtin_fabsf(g.x) + half), my = 1.0f + 2.4e-7f * (__builtin_fabsf(g.y) + half);
+    const float xl = g.x - half - mx, xh = g.x + half + mx, yl = g.y - half - my, yh = g.y + half + my;
     // (non-finite or off-image squares: no tile; kernel S emits only records that cover a pixel)
     if (xh >= 0.0f && xl < (float)R && yh >= 0.0f && yl < (float)R && xl == xl && xh == xh && yl == yl && yh == yh) {
         s.x0 = max(0, (int)__builtin_floorf(fmaxf(xl, 0.0f) * (1.0f / 64.0f)));

@@ -102,6 +102,7 @@ struct tsp_context {
     hipEvent_t ev[12] = {};
     float *image = nullptr;           // R*R*C float32 render target (what read-back, colormap and reduce see)
     double *image64 = nullptr;        // float64 master copy every kernel accumulates into (rounded once per render)
+    double *image64_entry = nullptr;  // image64 as tsp_render found it: what a failed block puts back (the call draws all of a block or none of it)
     float *mips = nullptr;            // 5440 floats
     bool have_mips = false;
     bool lut_mirror_symmetric = false;    // every mip level equals its left-right and top-bottom mirror images bit for bit
@@ -143,6 +144,9 @@ struct tsp_context {
                                       // unread: pays with a load-time spatial order (tsp_reorder_spatial); identical results
     int64_t chunk_culled_particles = 0;   // of the last render call
     bool overlap_mid_huge = false;    // option: kernels G and H2 on two streams (measured: no gain at 1.25e8, +6 % at 1e7)
+    int64_t slice_records = 0;        // option: deferred records kernels G / H2 take per launch (0 = 2^27 mid / 2^30 huge); a block of any size draws in slices
+    int debug_fail_stage = 0;         // test aid: the next render fails with TSP_ENOMEM after kernel S (1) / after kernel G (2); cleared by the failure
+    int stream_occ[3][2] = {};        // kernel S: workgroups resident per CU by [mode][one-channel window | all channels] (occupancy query, once per context)
     bool debug_no_raster = false;    // measurement aid: kernel S classifies and emits records but rasterises nothing (the image is then incomplete)
     int cu_count = 256;
     // RCCL

@@ -85,6 +85,9 @@ __device__ __forceinline__ int nearest_index(float u, int n) {
     return clampi((int)__builtin_floorf(u * (float)n), 0, n - 1);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libtopsy_splat is written for gfx950 (MI355X) only: its inline assembly uses that target's instructions (v_cvt_flr_i32_f32, DPP, ds_add_f64)"
+#endif
 // clampi((int)floorf(x), 0, hi) in two instructions instead of four: v_cvt_flr_i32_f32 converts with floor rounding (and saturates
 // like the plain conversion), v_med3_i32 clamps.  The same integers for every x; `hi` wave-uniform (_s) or per lane (_v).
 __device__ __forceinline__ int floor_clamp_s(float x, int hi) {

@@ -890,8 +890,7 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         const int min_cpb = std::max(1, std::min(8, n_chunks / (ctx->cu_count * 2)));
         int per_cu = ctx->stream_blocks_per_cu;
         if (per_cu <= 0) {
-            static int occ_of[2] = {0, 0};          // (per MODE: this is a function template) [one-channel window, all channels]
-            int &occ = occ_of[WCr == 1 ? 0 : 1];
+            int &occ = ctx->stream_occ[MODE][WCr == 1 ? 0 : 1];      // (per context: occupancy is a property of its device, and contexts render concurrently)
             if (occ <= 0) {
                 const void *fn = (WCr == 1) ? (const void *)splat_stream_kernel<MODE, 1> : (const void *)splat_stream_kernel<MODE, C>;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, SBLOCK, smem_s) != hipSuccess || occ <= 0) { (void)hipGetLastError(); occ = 4; }
@@ -957,16 +956,35 @@ static int run_pipeline(tsp_context *ctx, const Camera &cam, const int64_t *h_st
         TSP_HIP(hipEventRecord(ctx->ev[8], st));
         TSP_HIP(hipStreamWaitEvent(st_mid, ctx->ev[8], 0));
     }
+    if (ctx->debug_fail_stage == 1) { ctx->debug_fail_stage = 0; TSP_REQUIRE(false, TSP_ENOMEM, "injected failure after kernel S (debug_fail_stage)"); }
+    // A block of any size draws (sph.py:306-332 has no limit on a block): the tile kernels index their records and work items with
+    // 32 bits, so a longer list goes through them in slices -- bin, draw, next slice; the bins of a slice are bounded with it.
+    constexpr int NWr = (MODE == TSP_MODE_RGB) ? 2 : 1;            // weight floats per record
+    const long long n_mid = (long long)hc.n_mid, n_huge = (long long)hc.n_huge;
+    const long long mid_slice = ctx->slice_records > 0 ? ctx->slice_records : (1ll << 27);
+    const long long huge_slice = ctx->slice_records > 0 ? ctx->slice_records : (1ll << 30);
+    const float4 *mid_geom = (const float4 *)ws.mid_geom, *huge_geom = (const float4 *)ws.huge_geom;
+    const float *mid_w = (const float *)ws.mid_w, *huge_w = (const float *)ws.huge_w;
     TSP_HIP(hipEventRecord(ctx->ev[4], st_mid));
-    if (hc.n_mid > 0) {
-        if ((rc = launch_mid_gather(ctx, ta, MODE, second_channel, (const float4 *)ws.mid_geom, (const float *)ws.mid_w, (long long)hc.n_mid, st_mid))) return rc;
-    }
+    for (long long o = 0; o < n_mid; o += mid_slice)
+        if ((rc = launch_mid_gather(ctx, ta, MODE, second_channel, mid_geom + o, mid_w + o * NWr, std::min(mid_slice, n_mid - o), st_mid))) return rc;
     TSP_HIP(hipEventRecord(ctx->ev[5], st_mid));
+    if (ctx->debug_fail_stage == 2) { ctx->debug_fail_stage = 0; TSP_REQUIRE(false, TSP_ENOMEM, "injected failure after kernel G (debug_fail_stage)"); }
     TSP_HIP(hipEventRecord(ctx->ev[9], st));
-    if ((rc = launch_gather_kernels(ctx, ta, MODE, second_channel, (const float4 *)ws.huge_geom, (const float *)ws.huge_w, (long long)hc.n_huge))) return rc;
-    if (MODE == TSP_MODE_RGB && (hc.n_mid > 0 || hc.n_huge > 0)) {
+    TSP_HIP(hipEventRecord(ctx->ev[10], st));      // (kernel H2's launcher records it again after its launch)
+    for (long long o = 0; o < n_huge; o += huge_slice)
+        if ((rc = launch_gather_kernels(ctx, ta, MODE, second_channel, huge_geom + o, huge_w + o * NWr, std::min(huge_slice, n_huge - o)))) return rc;
+    if (MODE == TSP_MODE_RGB && (n_mid > 0 || n_huge > 0)) {
         if (ctx->overlap_mid_huge) TSP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));
-        if ((rc = add_rect_counts(ctx, (const float4 *)ws.mid_geom, (long long)hc.n_mid, (const float4 *)ws.huge_geom, (long long)hc.n_huge))) return rc;
+        // (the rectangle counts are 32-bit: one pass while both lists are single slices, else one pass per slice)
+        if (n_mid <= mid_slice && n_huge <= huge_slice) {
+            if ((rc = add_rect_counts(ctx, mid_geom, n_mid, huge_geom, n_huge))) return rc;
+        } else {
+            for (long long o = 0; o < n_mid; o += mid_slice)
+                if ((rc = add_rect_counts(ctx, mid_geom + o, std::min(mid_slice, n_mid - o), nullptr, 0))) return rc;
+            for (long long o = 0; o < n_huge; o += huge_slice)
+                if ((rc = add_rect_counts(ctx, nullptr, 0, huge_geom + o, std::min(huge_slice, n_huge - o)))) return rc;
+        }
     }
     TSP_HIP(hipEventRecord(ctx->ev[6], st));
     if (ctx->overlap_mid_huge) TSP_HIP(hipStreamWaitEvent(st, ctx->ev[5], 0));     // join: later work on `st` sees both
