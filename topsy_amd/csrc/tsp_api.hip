@@ -750,6 +750,11 @@ int tsp_set_option(tsp_context *ctx, const char *name, int64_t value) {
         ctx->mid_item_scale = (double)value * 1e-3;
         return TSP_OK;
     }
+    if (!strcmp(name, "mid_narrow_px_milli")) {    // mid footprints below this many 1/1000 px go to kernel N (0 = none)
+        TSP_REQUIRE(value >= 0 && value <= 64000, TSP_EINVAL, "%s out of range", name);
+        ctx->mid_narrow_px = (float)value * 1e-3f;
+        return TSP_OK;
+    }
     if (!strcmp(name, "mid_item_records")) {
         TSP_REQUIRE(value == 0 || (value >= 64 && value <= 8192 && (value & (value - 1)) == 0), TSP_EINVAL, "%s: 0 or a power of two from 64 to 8192", name);
         ctx->mid_item_records = (int)value;

@@ -127,21 +127,23 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
         wts += (size_t)band * a.hband_stride * NW;
         n_rec = (unsigned)a.hband_count[band];
     }
-    const unsigned n_runs = (n_rec + HDEAL - 1) / HDEAL, usplit = (unsigned)a.split;
-    const unsigned lane_run = (unsigned)(lane / HDEAL) * usplit;       // (loop-invariant: the 32-bit vector multiply runs at quarter rate)
+    const unsigned n_runs = (n_rec + HDEAL - 1) / HDEAL, usplit = (unsigned)a.split, n_last = max(n_rec, 1u) - 1u;
+    // record index of this lane in batch run0: ((run0 + lane / HDEAL) * split + sp) * HDEAL + lane % HDEAL = a wave-uniform base + lane_off
+    const unsigned lane_off = (unsigned)(lane / HDEAL) * usplit * HDEAL + (unsigned)(lane & (HDEAL - 1));      // (loop-invariant)
+    auto batch_base = [&](unsigned run0) -> unsigned { return (run0 * usplit + sp) * HDEAL; };
     auto fetch = [&](unsigned run0, float4 &g, float &gw1, float &gw2) {
-        const unsigned ri = (run0 * usplit + sp + lane_run) * HDEAL + (lane & (HDEAL - 1));
-        // unconditional loads (a slot past the end re-reads the last record and is emptied below): under a branch the
-        // compiler cannot count the loads in flight and waits for this prefetch right after issuing it
-        g = make_float4(0.f, 0.f, 0.f, 0.f); gw1 = gw2 = 0.0f;
-        if (ri < n_rec) {
-            g = geom[ri];
-            gw1 = wts[ri * NW];
-            if (NW == 2) gw2 = wts[ri * NW + 1];
-        }
+        // unconditional loads (a slot past the end re-reads the last record; the batch empties such slots when it starts): under a
+        // branch the compiler cannot count the loads in flight and waits for this prefetch right after issuing it
+        const unsigned rc = min(batch_base(run0) + lane_off, n_last);
+        g = geom[rc];
+        gw1 = (NACC >= 2) ? wts[rc * NW] : 0.0f;
+        gw2 = (NW == 2) ? wts[rc * NW + 1] : 0.0f;
     };
     float4 g_next; float gw1_next, gw2_next;
     fetch(0, g_next, gw1_next, gw2_next);
+    // (the first batch lands before the loop: with loads of the preheader still in flight at the loop header the compiler's
+    // counter model gives up and waits for every prefetch right after issuing it -- vmcnt(0) at the top of each batch: round 6)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     // The record loop is cut into segments of >= FOLD_EVERY footprints (<= FOLD_EVERY + 63); the accumulators go to the
     // float64 target between segments: ONE flush site, outside the hot loops (under the innermost loop
     // its offsets filled the scalar file and the accumulators were parked in scratch around every 64-record batch)
@@ -149,8 +151,9 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
     do {
     int since_fold = 0;
     for (; run0 * usplit < n_runs && since_fold < FOLD_EVERY; run0 += 64 / HDEAL) {
-        const float4 g = g_next;
+        float4 g = g_next;
         const float gw1 = gw1_next, gw2 = gw2_next;
+        if (batch_base(run0) + lane_off >= n_rec) g.z = 0.0f;      // (a slot past the end of the list)
         fetch(run0 + 64 / HDEAL, g_next, gw1_next, gw2_next);      // the next 64 records load while these are rasterised
         const float g_half = 0.5f * g.z;
         bool hit;
@@ -386,7 +389,8 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 #define TSP_G_OCC3 5
 #endif
 constexpr int GCHUNK_MAX = 1024;          // records per work item of kernel G (fewer for short lists: enough items to fill the device)
-constexpr int G_LDS_TILES = 8192;         // the binning passes keep their tile counters in LDS up to this many tiles (global atomics beyond)
+constexpr int G_LDS_TILES = 16384;        // the binning passes keep their tile counters in LDS up to this many tiles (global atomics beyond): 128 KB in the fill pass
+                                          // (kernel N's 16 x 16 strips at 2048^2; with global atomics its rgb binning took 20 ms instead of 1)
 
 template <int MODE, int NACC, int HR, int OCC, bool QUAD, bool CNT>
 __global__ __launch_bounds__(H2T, OCC) void splat_mid_gather_kernel(TileArgs a) {
@@ -446,22 +450,21 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mid_gather_kernel(TileArgs a) 
     const float *wts = a.w + first * NW;
     const unsigned n_rec = (unsigned)min(a.item_records, a.hband_count[strip] - chunk * a.item_records);
     auto fetch = [&](unsigned b0, float4 &g, float &gw1, float &gw2) {      // records b0 + lane of the item (one per lane)
-        const unsigned ri = b0 + lane;
-        g = make_float4(0.f, 0.f, 0.f, 0.f); gw1 = gw2 = 0.0f;
-        if (ri < n_rec) {
-            g = geom[ri];
-            gw1 = wts[ri * NW];
-            if (NW == 2) gw2 = wts[ri * NW + 1];
-        }
+        const unsigned rc = min(b0 + lane, n_rec - 1u);       // (unconditional loads, as in kernel H2; an item holds >= 1 record)
+        g = geom[rc];
+        gw1 = (NACC >= 2) ? wts[rc * NW] : 0.0f;
+        gw2 = (NW == 2) ? wts[rc * NW + 1] : 0.0f;
     };
     float4 g_next; float gw1_next, gw2_next;
     fetch(0, g_next, gw1_next, gw2_next);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see kernel H2
     unsigned run0 = 0;                    // first record of the next batch of 64
     do {
     int since_fold = 0;
     for (; run0 < n_rec && since_fold < FOLD_EVERY; run0 += 64) {
-        const float4 g = g_next;
+        float4 g = g_next;
         const float gw1 = gw1_next, gw2 = gw2_next;
+        if (run0 + lane >= n_rec) g.z = 0.0f;                 // (a slot past the end of the item)
         fetch(run0 + 64, g_next, gw1_next, gw2_next);
         const float g_half = 0.5f * g.z;
         bool hit;
@@ -568,6 +571,227 @@ __global__ __launch_bounds__(H2T, OCC) void splat_mid_gather_kernel(TileArgs a) 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// kernel N: the NARROW mid footprints (below ~32 px) -- four records per wave step
+// ---------------------------------------------------------------------------------------------
+// Kernel G gives a whole wave to one (footprint, strip) pair: for a footprint of 18 px a quarter of its 64 pixel columns are covered
+// and the pair's set-up (seven v_readlane, row table, column weights) costs as much as its rows -- 3.4 SIMD-clocks per fragment at
+// 16 px against 0.86 at 48 px (tools/gpu_huge_classes.py, round 6), and zoomed cameras turn most of a snapshot into such records.
+// Here a wave owns a strip of 16 columns x HR rows and its four DPP rows of 16 lanes are four record SLOTS: lane (s, c) holds the
+// partial sums of pixel column c over slot s's records.  A step draws four records of the strip's bin at once:
+//   * every lane loads ITS slot's record (16 lanes read one address): no v_readlane, every parameter is a vector value;
+//   * lane (s, c) evaluates the LUT row of pixel rows c and c + 16 for its slot's record -> per-slot row table in LDS (the address
+//     of the row, or of a block of zeros when the record does not cover that pixel row), and its column + weight;
+//   * the row walk is wave-uniform over the UNION of the four records' rows, a quad of lanes carrying the four rows of a group as
+//     in kernel G (v_add_u32_dpp quad_perm + a 4-byte LDS read + v_fmac per row); a slot that does not cover a row reads zeros.
+// One instruction stream per four pairs instead of one per pair.  The bins hold only the records that reach the strip (the binning
+// passes make kernel G's per-pair square-and-disc test themselves: `exact`), so no lane waits for another slot's miss.  A record whose
+// weight is not finite would turn "0 x weight" into NaN where only another slot covers a row: such a step is drawn slot by slot.
+// At the end of the item the four slots' partial strips are summed across the DPP rows and go to the float64 target.
+constexpr int NSW = 16;                   // pixel columns of kernel N's strips (= lanes per record slot)
+// Kernel N's LUT in LDS (mirror-symmetric kernel image: the top-left quadrants).  A ds_read_b32 is served in two groups of 32 lanes
+// over 32 banks, i.e. two record slots per group, and two slots reading two different LUT rows collide: 35 % of the LDS cycles of
+// the first version were bank conflicts (SQ_LDS_BANK_CONFLICT), on a kernel whose LDS pipe is busy 3/4 of the time.  So the
+// quadrants are stored TWICE, interleaved in LINES of 32 floats: floats 0-15 of a line serve the even slots, 16-31 (the same
+// values) the odd slots -- a slot only ever touches its own 16 banks.  A LUT row takes whole half-lines (16 floats): level 0 (32
+// floats per quadrant row) two, levels 1-3 (16, 8, 4 floats) one each, so that a row's address is base(level) + (ty << 7 or 8);
+// then two lines of zeros (what a slot reads in a pixel row its record does not cover).
+constexpr int NQ_L1 = 64, NQ_L2 = 80, NQ_L3 = 88, NQ_ZERO = 92, NQ_LINES = 94;       // first line of levels 1, 2, 3, of the zeros; lines in all
+
+template <int MODE, int NACC, int HR, int OCC, bool QUAD, bool CNT>
+__global__ __launch_bounds__(H2T, OCC) void splat_narrow_gather_kernel(TileArgs a) {
+    constexpr int C = (MODE == TSP_MODE_RGB) ? 4 : 2;
+    constexpr int NW = (MODE == TSP_MODE_RGB) ? 2 : 1;
+    constexpr int NG = HR / 4, NE = HR / 16;          // row groups; pixel rows a lane evaluates per record
+    static_assert(HR == 16 || HR == 32, "rows per wave strip");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TSIZE = QUAD ? NQ_ZERO * 32 : MIP_TOTAL;             // (floats before the 64 zeros)
+    static_assert(NQ_LINES == NQ_ZERO + 2, "two lines of zeros end the table");
+    float *T = smem;
+    float *Z = smem + TSIZE;                                            // 64 zeros: what a slot reads in a row its record does not cover
+    int *rt_all = reinterpret_cast<int *>(smem + TSIZE + 64);           // per wave: 4 slots x HR row addresses
+    typedef const __attribute__((address_space(3))) float LdsF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slot = lane >> 4, col = lane & 15;
+    // (QUAD: this slot's half of every line)
+    const int T_lds = (int)(unsigned)(unsigned long long)(LdsF *)T + (QUAD ? (slot & 1) * 64 : 0);
+    const int Z_lds = (int)(unsigned)(unsigned long long)(LdsF *)Z + (QUAD ? (slot & 1) * 64 : 0);
+    const int R = a.cam.R;
+    const int n_items = a.item_base[a.n_tiles];
+    if ((int)blockIdx.x * (H2T / 64) >= n_items) return;
+    const int item = min((int)blockIdx.x * (H2T / 64) + wv, n_items - 1);
+    const bool idle_wave = (int)blockIdx.x * (H2T / 64) + wv >= n_items;
+    const int strip = a.item_tile[item];
+    const int chunk = item - a.item_base[strip];
+    if (QUAD) {
+        for (int i = tid; i < MIPQ_TOTAL; i += H2T) {
+            const int lvl = i < 1024 ? 0 : (i < 1280 ? 1 : (i < 1344 ? 2 : 3));
+            const int hn = 32 >> lvl, k = i - mipq_offset(lvl), r = k / hn, c = k % hn;
+            const float t = a.mips[mip_offset(lvl) + r * (2 * hn) + c];
+            const int line = lvl == 0 ? 2 * r + (c >> 4) : (lvl == 1 ? NQ_L1 : (lvl == 2 ? NQ_L2 : NQ_L3)) + r;
+            T[line * 32 + (c & 15)] = t; T[line * 32 + 16 + (c & 15)] = t;
+        }
+    } else {
+        for (int i = tid; i < MIP_TOTAL; i += H2T) T[i] = a.mips[i];
+    }
+    if (tid < 64) Z[tid] = 0.0f;
+    int *rt = rt_all + wv * (4 * HR) + slot * HR;
+    const int *rt_quad = rt + (col & 3);
+    const int sx = (strip % a.tiles_x) * NSW, sy = (strip / a.tiles_x) * HR;
+    const float pxc = (sx + col < R) ? (float)(sx + col) + 0.5f : __builtin_inff();
+    float pyc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) pyc[e] = (sy + col + 16 * e < R) ? (float)(sy + col + 16 * e) + 0.5f : __builtin_inff();
+
+    constexpr int FOLD_EVERY = TSP_FOLD_EVERY;
+    float acc[HR][NACC];
+#pragma unroll
+    for (int p = 0; p < HR; ++p)
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) acc[p][c] = 0.0f;
+    unsigned long long n_frag = 0;
+    __syncthreads();                                       // the only workgroup barrier
+    if (idle_wave) return;
+
+    const size_t first = (size_t)a.hband_base[strip] + (size_t)chunk * a.item_records;
+    constexpr int NWN = NW + 1;           // weights per record of kernel N's bins: (w0, w1[, w2]); the geometry carries 1 / P in their place
+    const float4 *geom = a.geom + first;
+    const float *wts = a.w + first * NWN;
+    const unsigned n_rec = (unsigned)min(a.item_records, a.hband_count[strip] - chunk * a.item_records);
+    // record r0 + slot of the item (one per slot).  Unconditional loads (a slot past the end re-reads the last record and is
+    // emptied where it is used): under a branch the compiler waits for this prefetch right after issuing it
+    auto fetch = [&](unsigned r0, float4 &g, float &gw0, float &gw1, float &gw2) {
+        const unsigned ri = min(r0 + slot, n_rec - 1u);
+        // (32-bit byte offsets from the item's first record -- an item holds <= 8192 records: one scalar base + one vector offset per load)
+        g = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(geom) + (ri << 4));
+        const float *wp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(wts) + ri * (NWN * 4u));
+        gw0 = wp[0];
+        gw1 = (NACC >= 2) ? wp[1] : 0.0f;
+        gw2 = (NACC >= 3) ? wp[2] : 0.0f;
+    };
+    const int n_pass = a.cnt->mid_odd_weights ? 4 : 1;
+    float4 g_next; float gw0_next, gw1_next, gw2_next;
+    fetch(0, g_next, gw0_next, gw1_next, gw2_next);
+    // (the first records land before the loop: with loads of the preheader still in flight at the loop header the compiler's
+    // counter model gives up and waits for every prefetch right after issuing it -- vmcnt(0) at the top of each step)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    unsigned r0 = 0;                      // first record of the next step
+    do {
+    int since_fold = 0;
+    for (; r0 < n_rec && since_fold < FOLD_EVERY; r0 += 4, ++since_fold) {
+        float4 g_all = g_next;
+        const float gw0_all = gw0_next, gw1_all = gw1_next, gw2_all = gw2_next;
+        if (r0 + slot >= n_rec) g_all.z = 0.0f;                     // (a slot past the end of the item: covers nothing)
+        fetch(r0 + 4, g_next, gw0_next, gw1_next, gw2_next);
+        // weights that are not finite (the fill pass raises the flag when the list holds any): every step is drawn slot by slot --
+        // then "0 x weight" only occurs inside the slot's own rows, which the wave-uniform row test skips when uncovered
+        for (int pass = 0; pass < n_pass; ++pass) {
+            float4 g = g_all;
+            if (n_pass == 4 && slot != pass) g.z = 0.0f;            // (an empty slot: covers nothing, weight 0)
+            const float half = 0.5f * g.z;
+            const float invP = g.w;                                 // (1.0f / P, formed by the fill pass)
+            // mip level (tsp_math.h level_for, branch-free: every lane has its own record) and that level's LUT geometry
+            const int lvl = (g.z > P_L0 ? 0 : 1) + (g.z > P_L1 ? 0 : 1) + (g.z > P_L2 ? 0 : 1);
+            const int n = 64 >> lvl;
+            const float nf = (float)n;
+            // LDS address of LUT row ty of this level: whole pyramid -- first float of the level 0, 4096, 5120, 5376, rows of n floats;
+            // quadrants (the interleaved lines above) -- first line of the level, one line per row (level 0: two)
+            const int tshift = QUAD ? (lvl == 0 ? 8 : 7) : 8 - lvl;
+            const int tbase = QUAD ? T_lds + (lvl == 0 ? 0 : (lvl == 1 ? NQ_L1 : (lvl == 2 ? NQ_L2 : NQ_L3))) * 128
+                                   : T_lds + ((lvl > 0 ? 4096 : 0) + (lvl > 1 ? 1024 : 0) + (lvl > 2 ? 256 : 0)) * 4;
+            auto row_addr = [&](int ty) -> int { return tbase + (ty << tshift); };
+            float wq[3];
+            wq[0] = gw0_all;
+            wq[1] = (NACC >= 2) ? ((MODE == TSP_MODE_RGB) ? gw1_all : gw0_all * gw1_all) : 0.0f;
+            wq[2] = (NACC >= 3) ? gw2_all : 0.0f;
+            // ---- rows: lane (s, c) evaluates pixel rows c (and c + 16) for slot s's record (canonical nearest-texel rule, tsp_math.h) ----
+            unsigned covmask = 0, ownmask = 0;
+            asm volatile("" ::: "memory");          // (in-order LDS: the previous step's table reads are done)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const float d = pyc[e] - g.y;
+                int ty = floor_clamp_v(((d + half) * invP) * nf, n - 1);
+                if (QUAD) ty = min(ty, n - 1 - ty);
+                const bool cov = __builtin_fabsf(d) < half;
+                rt[col + 16 * e] = cov ? row_addr(ty) : Z_lds;
+                const unsigned long long b = __ballot(cov);
+                covmask |= (unsigned)((b | (b >> 16) | (b >> 32) | (b >> 48)) & 0xffffull) << (16 * e);       // the union of the four slots' rows
+                if (CNT) ownmask |= (unsigned)((b >> (16 * slot)) & 0xffffull) << (16 * e);
+            }
+            asm volatile("" ::: "memory");
+            if (covmask == 0) continue;
+            // ---- this lane's column: texel column (byte offset in a LUT row) and weights (+0 where the column is not covered) ----
+            int tx4;
+            float wl[NACC];
+            {
+                const float d = pxc - g.x;
+                const bool covered = __builtin_fabsf(d) < half;
+                int tx = floor_clamp_v(((d + half) * invP) * nf, n - 1);
+                if (QUAD) tx = min(tx, n - 1 - tx);
+                tx4 = tx * 4;
+                if (QUAD) tx4 += (tx & 16) << 2;            // (level 0: floats 16-31 of a row sit in the next line)
+#pragma unroll
+                for (int c = 0; c < NACC; ++c) wl[c] = covered ? wq[c] : 0.0f;
+                if (CNT) n_frag += covered ? (unsigned long long)__popc(ownmask) : 0ull;
+            }
+            // ---- row walk over the union of the slots' rows: a group's row addresses sit in the quads (lane (s, c): row 4 k + (c & 3) of slot s) ----
+            int roq[2];
+            roq[0] = rt_quad[0];
+#define TSP_N_ROW(K, T_)                                                                                        \
+            if ((covmask >> (4 * (K) + (T_))) & 1) {                                                            \
+                _Pragma("unroll") for (int c = 0; c < NACC; ++c) fmac_plain(acc[4 * (K) + (T_)][c], kv[T_], wl[c]); \
+            }
+#define TSP_N_GROUP(K)                                                                                          \
+            if constexpr ((K) < NG) {                                                                           \
+                if constexpr ((K) + 1 < NG) roq[((K) + 1) & 1] = rt_quad[4 * ((K) + 1)];                         \
+                if (((covmask >> (4 * (K))) & 15u) != 0u) {                                                     \
+                    asm volatile("" : "+v"(roq[(K) & 1]));                                                      \
+                    int ad[4]; float kv[4];                                                                     \
+                    asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(0) : "=v"(ad[0]) : "v"(roq[(K) & 1]), "v"(tx4)); \
+                    asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(1) : "=v"(ad[1]) : "v"(roq[(K) & 1]), "v"(tx4)); \
+                    asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(2) : "=v"(ad[2]) : "v"(roq[(K) & 1]), "v"(tx4)); \
+                    asm volatile("v_add_u32_dpp %0, %1, %2 " TSP_DPP_QUAD(3) : "=v"(ad[3]) : "v"(roq[(K) & 1]), "v"(tx4)); \
+                    _Pragma("unroll") for (int t = 0; t < 4; ++t) kv[t] = *reinterpret_cast<LdsF *>(ad[t]);    \
+                    TSP_N_ROW(K, 0) TSP_N_ROW(K, 1) TSP_N_ROW(K, 2) TSP_N_ROW(K, 3)                               \
+                }                                                                                               \
+            }
+            TSP_N_GROUP(0) TSP_N_GROUP(1) TSP_N_GROUP(2) TSP_N_GROUP(3)
+            TSP_N_GROUP(4) TSP_N_GROUP(5) TSP_N_GROUP(6) TSP_N_GROUP(7)
+#undef TSP_N_GROUP
+#undef TSP_N_ROW
+        }
+    }
+    // ---- the four slots' partial strips summed across the DPP rows, then into the render target: lane (s, c) adds rows s, s + 4, ... ----
+    {
+        int Rl = R;
+        asm volatile("" : "+s"(Rl));
+        double *img = a.img + ((size_t)sy * Rl + (sx + col)) * C;
+        asm volatile("" : "+v"(img));
+#pragma unroll
+        for (int ty = 0; ty < HR; ++ty) {
+            const int gx = sx + col, gy = sy + ty;
+#pragma unroll
+            for (int c = 0; c < NACC; ++c) {
+                float v = acc[ty][c];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                acc[ty][c] = 0.0f;
+                if ((ty & 3) == slot && gx < Rl && gy < Rl && v != 0.0f) gatomic_add(img + ((size_t)ty * Rl) * C + c, v);
+            }
+        }
+    }
+    } while (r0 < n_rec);
+    if (CNT) {
+        for (int o = 32; o; o >>= 1) n_frag += __shfl_xor((long long)n_frag, o);
+        if (lane == 0 && n_frag) { atomicAdd(&a.cnt->n_fragments, n_frag); atomicAdd(&a.cnt->n_frag_class[1], n_frag); }
+#ifdef TSP_N_DEBUG       // analysis build: records of the bins (= (record, strip) pairs) instead of the unused fourth fragment class
+        if (lane == 0) atomicAdd(&a.cnt->n_frag_class[3], (unsigned long long)n_rec);
+#endif
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // band bins of the huge records
 // ---------------------------------------------------------------------------------------------
@@ -670,26 +894,43 @@ static int bin_huge_records(tsp_context *ctx, TileArgs &ta, const float4 *huge_g
 // with one item per workgroup: 12.35 ms (the four strips of a tile differ in work); per strip with one item per wave: 10.0.
 
 struct TileSpan { int x0, x1, y0, y1; };
-__device__ __forceinline__ TileSpan tile_span(const float4 g, int R, int th, int tiles_x, int tiles_y) {
+// what the binning passes of one kernel-G launch share: strip shape, the footprint widths it takes, and (exact) whether a record
+// goes only into the bins of the strips its square AND the kernel's disc reach (kernel N draws every record of a bin unasked)
+struct BinArgs {
+    int R, tw, th, tiles_x, tiles_y;
+    float pmin, pmax;          // footprints with pmin <= P < pmax
+    float disc_k2;             // as TileArgs::disc_k2 (0: the square alone decides)
+    int exact;
+    int narrow;                // kernel N's record layout: geometry (pcx, pcy, P, 1 / P), weights (w0, w1[, w2]) -- see tile_fill_kernel
+};
+__device__ __forceinline__ TileSpan tile_span(const float4 g, const BinArgs &b) {
     TileSpan s; s.x0 = s.y0 = 1; s.x1 = s.y1 = 0;
+    if (!(g.z >= b.pmin && g.z < b.pmax)) return s;
     // (margin: one pixel plus two ulps of the coordinate -- it covers the rounding of g -+ half at any magnitude)
     const float half = 0.5f * g.z, mx = 1.0f + 2.4e-7f * (__builtin_fabsf(g.x) + half), my = 1.0f + 2.4e-7f * (__builtin_fabsf(g.y) + half);
     const float xl = g.x - half - mx, xh = g.x + half + mx, yl = g.y - half - my, yh = g.y + half + my;
     // (non-finite or off-image squares: no tile; kernel S emits only records that cover a pixel)
-    if (xh >= 0.0f && xl < (float)R && yh >= 0.0f && yl < (float)R && xl == xl && xh == xh && yl == yl && yh == yh) {
-        s.x0 = max(0, (int)__builtin_floorf(fmaxf(xl, 0.0f) * (1.0f / 64.0f)));
-        s.x1 = min(tiles_x - 1, (int)__builtin_floorf(fminf(xh, (float)R) * (1.0f / 64.0f)));
-        s.y0 = max(0, (int)__builtin_floorf(fmaxf(yl, 0.0f) / (float)th));
-        s.y1 = min(tiles_y - 1, (int)__builtin_floorf(fminf(yh, (float)R) / (float)th));
+    if (xh >= 0.0f && xl < (float)b.R && yh >= 0.0f && yl < (float)b.R && xl == xl && xh == xh && yl == yl && yh == yh) {
+        s.x0 = max(0, (int)__builtin_floorf(fmaxf(xl, 0.0f) / (float)b.tw));
+        s.x1 = min(b.tiles_x - 1, (int)__builtin_floorf(fminf(xh, (float)b.R) / (float)b.tw));
+        s.y0 = max(0, (int)__builtin_floorf(fmaxf(yl, 0.0f) / (float)b.th));
+        s.y1 = min(b.tiles_y - 1, (int)__builtin_floorf(fminf(yh, (float)b.R) / (float)b.th));
     }
     return s;
 }
+// the test kernels G and H2 make per (record, strip) pair: the footprint square and the disc inscribed in it reach the strip
+__device__ __forceinline__ bool strip_hit(const float4 g, int tx, int ty, const BinArgs &b) {
+    if (!b.exact) return true;
+    const float sx0 = (float)(tx * b.tw), sx1 = (float)(tx * b.tw + b.tw), sy0 = (float)(ty * b.th), sy1 = (float)(ty * b.th + b.th);
+    const float half = 0.5f * g.z;
+    const float sdx = fmaxf(fmaxf(sx0 - g.x, g.x - sx1), 0.0f), sdy = fmaxf(fmaxf(sy0 - g.y, g.y - sy1), 0.0f);
+    return g.z > 0.0f && sdx < half && sdy < half && !(b.disc_k2 > 0.0f && sdx * sdx + sdy * sdy >= b.disc_k2 * g.z * g.z);
+}
 // pass 1: records per tile (counted in LDS first when the image has few enough tiles: one global atomic per workgroup and tile)
-__global__ __launch_bounds__(256) void tile_count_kernel(const float4 *__restrict__ geom, long long n, int R, int th, int tiles_x, int tiles_y,
-                                                         int *__restrict__ tile_count) {
+__global__ __launch_bounds__(256) void tile_count_kernel(const float4 *__restrict__ geom, long long n, BinArgs b, int *__restrict__ tile_count) {
     constexpr int PER = 4;
     extern __shared__ int s_tile[];
-    const int n_tiles = tiles_x * tiles_y;
+    const int tiles_x = b.tiles_x, n_tiles = tiles_x * b.tiles_y;
     const bool lds = n_tiles <= G_LDS_TILES;
     if (lds) {
         for (int t = threadIdx.x; t < n_tiles; t += 256) s_tile[t] = 0;
@@ -700,9 +941,11 @@ __global__ __launch_bounds__(256) void tile_count_kernel(const float4 *__restric
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         if (first + k >= n) continue;
-        const TileSpan sp = tile_span(geom[first + k], R, th, tiles_x, tiles_y);
+        const float4 g = geom[first + k];
+        const TileSpan sp = tile_span(g, b);
         for (int ty = sp.y0; ty <= sp.y1; ++ty)
-            for (int tx = sp.x0; tx <= sp.x1; ++tx) atomicAdd(&cnt[ty * tiles_x + tx], 1);
+            for (int tx = sp.x0; tx <= sp.x1; ++tx)
+                if (strip_hit(g, tx, ty, b)) atomicAdd(&cnt[ty * tiles_x + tx], 1);
     }
     if (lds) {
         __syncthreads();
@@ -748,12 +991,13 @@ __global__ __launch_bounds__(1024) void tile_prefix_kernel(const int *__restrict
 }
 // pass 3: the records into their bins (with LDS counters a workgroup reserves its slots per tile with one global atomic)
 template <int NW>
-__global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict__ geom, const float *__restrict__ w, long long n, int R, int th,
-                                                        int tiles_x, int tiles_y, float4 *__restrict__ out_geom, float *__restrict__ out_w,
-                                                        const long long *__restrict__ tile_base, int *__restrict__ tile_cursor) {
+__global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict__ geom, const float *__restrict__ w, long long n, BinArgs b,
+                                                        float4 *__restrict__ out_geom, float *__restrict__ out_w,
+                                                        const long long *__restrict__ tile_base, int *__restrict__ tile_cursor,
+                                                        unsigned long long *__restrict__ odd_flag) {
     constexpr int PER = 4;
     extern __shared__ int s_tile[];        // [n_tiles] counts, then [n_tiles] bases
-    const int n_tiles = tiles_x * tiles_y;
+    const int tiles_x = b.tiles_x, n_tiles = tiles_x * b.tiles_y;
     const bool lds = n_tiles <= G_LDS_TILES;
     int *s_cnt = s_tile, *s_base = s_tile + n_tiles;
     if (lds) {
@@ -768,10 +1012,11 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict
         sp[k].x0 = sp[k].y0 = 1; sp[k].x1 = sp[k].y1 = 0;
         if (first + k < n) {
             g[k] = geom[first + k];
-            sp[k] = tile_span(g[k], R, th, tiles_x, tiles_y);
+            sp[k] = tile_span(g[k], b);
             if (lds)
                 for (int ty = sp[k].y0; ty <= sp[k].y1; ++ty)
-                    for (int tx = sp[k].x0; tx <= sp[k].x1; ++tx) atomicAdd(&s_cnt[ty * tiles_x + tx], 1);
+                    for (int tx = sp[k].x0; tx <= sp[k].x1; ++tx)
+                        if (strip_hit(g[k], tx, ty, b)) atomicAdd(&s_cnt[ty * tiles_x + tx], 1);
         }
     }
     if (lds) {
@@ -787,23 +1032,40 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict
     for (int k = 0; k < PER; ++k) {
         if (first + k >= n || sp[k].y0 > sp[k].y1 || sp[k].x0 > sp[k].x1) continue;
         const float w0 = w[(first + k) * NW], w1 = (NW == 2) ? w[(first + k) * NW + 1] : 0.0f;
+        // kernel N's records: (pcx, pcy, P, 1 / P) + every weight in the weight array -- the IEEE division once per record copy
+        // here instead of once per record and LANE there (kernel N holds a record's parameters in all 16 lanes of its slot)
+        const float4 gn = make_float4(g[k].x, g[k].y, g[k].z, 1.0f / g[k].z);
+        // (kernel N draws four records per step: a weight that is not finite makes it draw every step slot by slot -- see there)
+        if (b.narrow && odd_flag && !(__builtin_fabsf(g[k].w) < __builtin_inff() && __builtin_fabsf(w0) < __builtin_inff() && __builtin_fabsf(w1) < __builtin_inff()))
+            *odd_flag = 1ull;
         for (int ty = sp[k].y0; ty <= sp[k].y1; ++ty)
             for (int tx = sp[k].x0; tx <= sp[k].x1; ++tx) {
+                if (!strip_hit(g[k], tx, ty, b)) continue;
                 const int t = ty * tiles_x + tx;
                 const long long slot = tile_base[t] + (lds ? s_base[t] + atomicAdd(&s_cnt[t], 1) : atomicAdd(&tile_cursor[t], 1));
-                out_geom[slot] = g[k];
-                out_w[slot * NW] = w0;
-                if (NW == 2) out_w[slot * NW + 1] = w1;
+                if (b.narrow) {
+                    out_geom[slot] = gn;
+                    out_w[slot * (NW + 1)] = g[k].w;
+                    out_w[slot * (NW + 1) + 1] = w0;
+                    if (NW == 2) out_w[slot * (NW + 1) + 2] = w1;
+                } else {
+                    out_geom[slot] = g[k];
+                    out_w[slot * NW] = w0;
+                    if (NW == 2) out_w[slot * NW + 1] = w1;
+                }
             }
     }
 }
 
 // bins the mid list by strip and builds the work items; sets ta.{geom, w, hband_count (records per strip), hband_base, item_*}
 template <int NW>
-static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geom, const float *mid_w, long long n_mid, int th, int *n_items_out,
-                           hipStream_t st) {
+static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geom, const float *mid_w, long long n_mid, int tw, int th, float pmin,
+                           float pmax, bool exact, int *n_items_out, hipStream_t st) {
     Workspace &ws = ctx->ws;
-    const int tiles_x = (ctx->R + 63) / 64, tiles_y = (ctx->R + th - 1) / th, n_tiles = tiles_x * tiles_y;
+    const int tiles_x = (ctx->R + tw - 1) / tw, tiles_y = (ctx->R + th - 1) / th, n_tiles = tiles_x * tiles_y;
+    BinArgs ba;
+    ba.R = ctx->R; ba.tw = tw; ba.th = th; ba.tiles_x = tiles_x; ba.tiles_y = tiles_y; ba.pmin = pmin; ba.pmax = pmax;
+    ba.disc_k2 = ta.disc_k2; ba.exact = exact ? 1 : 0; ba.narrow = exact ? 1 : 0;
     if (ws.mtile_capacity < n_tiles) {
         void *olds[] = {ws.mband_count, ws.mband_base, ws.mitem_base};
         for (void *q : olds)
@@ -823,8 +1085,13 @@ static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geo
     }
     TSP_HIP(hipMemsetAsync(ws.mband_count, 0, 2 * (size_t)ws.mtile_capacity * sizeof(int), st));
     const bool lds = n_tiles <= G_LDS_TILES;
+    if (!(ctx->kernel_attr_done & (1u << (8 + NW)))) {      // (more than 64 KB of dynamic LDS needs the attribute)
+        TSP_HIP(hipFuncSetAttribute((const void *)tile_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_TILES * (int)sizeof(int)));
+        TSP_HIP(hipFuncSetAttribute((const void *)tile_fill_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_LDS_TILES * (int)sizeof(int)));
+        ctx->kernel_attr_done |= 1u << (8 + NW);
+    }
     const unsigned grid = (unsigned)((n_mid + 1023) / 1024);
-    hipLaunchKernelGGL(tile_count_kernel, dim3(grid), dim3(256), lds ? n_tiles * sizeof(int) : 0, st, mid_geom, n_mid, ctx->R, th, tiles_x, tiles_y, ws.mband_count);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(grid), dim3(256), lds ? n_tiles * sizeof(int) : 0, st, mid_geom, n_mid, ba, ws.mband_count);
     // the sizes of the bins are known on the device only: the prefix pass runs once without the item table to size it, the
     // host reads the two totals (one small copy; the pipeline already synchronises once per frame for the record counts) and grows
     // the bins when needed, then the pass runs again and writes the table
@@ -841,12 +1108,13 @@ static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geo
         ws.mband_capacity = std::max<int64_t>(ws.mband_capacity, total_records + total_records / 4 + 1024);
         ws.mitem_capacity = std::max<int64_t>(ws.mitem_capacity, (int64_t)total_items + total_items / 4 + 1024);
         TSP_HIP(hipMalloc(&ws.mband_geom, (size_t)ws.mband_capacity * sizeof(float4)));
-        TSP_HIP(hipMalloc(&ws.mband_w, (size_t)ws.mband_capacity * 2 * sizeof(float)));
+        TSP_HIP(hipMalloc(&ws.mband_w, (size_t)ws.mband_capacity * 3 * sizeof(float)));      // (kernel N keeps up to three weights per record here)
         TSP_HIP(hipMalloc((void **)&ws.mitem_tile, (size_t)ws.mitem_capacity * sizeof(int)));
     }
     hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int *)ws.mband_count, n_tiles, ws.mband_base, ws.mitem_base, ws.mitem_tile, total_items, item_records);
-    hipLaunchKernelGGL((tile_fill_kernel<NW>), dim3(grid), dim3(256), lds ? 2 * n_tiles * sizeof(int) : 0, st, mid_geom, mid_w, n_mid, ctx->R, th, tiles_x, tiles_y,
-                       (float4 *)ws.mband_geom, (float *)ws.mband_w, (const long long *)ws.mband_base, ws.mband_count + ws.mtile_capacity);
+    hipLaunchKernelGGL((tile_fill_kernel<NW>), dim3(grid), dim3(256), lds ? 2 * n_tiles * sizeof(int) : 0, st, mid_geom, mid_w, n_mid, ba,
+                       (float4 *)ws.mband_geom, (float *)ws.mband_w, (const long long *)ws.mband_base, ws.mband_count + ws.mtile_capacity,
+                       &ctx->counters->mid_odd_weights);
     TSP_HIP(hipGetLastError());
     ta.geom = (const float4 *)ws.mband_geom; ta.w = (const float *)ws.mband_w;
     ta.hband_count = ws.mband_count; ta.hband_stride = 0; ta.hband_base = ws.mband_base;
@@ -857,12 +1125,12 @@ static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geo
 }
 
 template <int MODE, int NACC, int HR, int OCC>
-static int launch_mid_gather_kernel(tsp_context *ctx, TileArgs ta, const float4 *mid_geom, const float *mid_w, long long n_mid, hipStream_t st) {
+static int launch_mid_gather_kernel(tsp_context *ctx, TileArgs ta, const float4 *mid_geom, const float *mid_w, long long n_mid, float pmin, hipStream_t st) {
     const bool quad = ctx->lut_mirror_symmetric && !ctx->debug_gather_full_lut;
     const size_t smem = (size_t)(quad ? MIPQ_TOTAL : MIP_TOTAL) * sizeof(float) + (H2T / 64) * 64 * sizeof(int);
     int rc, n_items = 0;
     ta.n_records = n_mid;
-    if ((rc = bin_mid_records<(MODE == TSP_MODE_RGB) ? 2 : 1>(ctx, ta, mid_geom, mid_w, n_mid, HR, &n_items, st))) return rc;
+    if ((rc = bin_mid_records<(MODE == TSP_MODE_RGB) ? 2 : 1>(ctx, ta, mid_geom, mid_w, n_mid, 64, HR, pmin, __builtin_inff(), false, &n_items, st))) return rc;
     if (n_items == 0) return TSP_OK;
     const dim3 grid((n_items + H2T / 64 - 1) / (H2T / 64));
     if (quad) {
@@ -876,12 +1144,43 @@ static int launch_mid_gather_kernel(tsp_context *ctx, TileArgs ta, const float4 
     return TSP_OK;
 }
 
+// kernel N for the records below `pmax` px (its own bins: 16-column strips, only the records that reach a strip)
+template <int MODE, int NACC, int HR, int OCC>
+static int launch_narrow_gather_kernel(tsp_context *ctx, TileArgs ta, const float4 *mid_geom, const float *mid_w, long long n_mid, float pmax, hipStream_t st) {
+    const bool quad = ctx->lut_mirror_symmetric && !ctx->debug_gather_full_lut;
+    const size_t smem = (size_t)(quad ? NQ_LINES * 32 : MIP_TOTAL + 64) * sizeof(float) + (H2T / 64) * 4 * HR * sizeof(int);
+    int rc, n_items = 0;
+    ta.n_records = n_mid;
+    if ((rc = bin_mid_records<(MODE == TSP_MODE_RGB) ? 2 : 1>(ctx, ta, mid_geom, mid_w, n_mid, NSW, HR, 0.0f, pmax, true, &n_items, st))) return rc;
+    if (n_items == 0) return TSP_OK;
+    const dim3 grid((n_items + H2T / 64 - 1) / (H2T / 64));
+    if (quad) {
+        if (ta.count_frag) hipLaunchKernelGGL((splat_narrow_gather_kernel<MODE, NACC, HR, OCC, true, true>), grid, dim3(H2T), smem, st, ta);
+        else hipLaunchKernelGGL((splat_narrow_gather_kernel<MODE, NACC, HR, OCC, true, false>), grid, dim3(H2T), smem, st, ta);
+    } else {
+        if (ta.count_frag) hipLaunchKernelGGL((splat_narrow_gather_kernel<MODE, NACC, HR, OCC, false, true>), grid, dim3(H2T), smem, st, ta);
+        else hipLaunchKernelGGL((splat_narrow_gather_kernel<MODE, NACC, HR, OCC, false, false>), grid, dim3(H2T), smem, st, ta);
+    }
+    TSP_HIP(hipGetLastError());
+    return TSP_OK;
+}
+
 template <int MODE>
 static int launch_mid_gather_mode(tsp_context *ctx, TileArgs ta, bool second_channel, const float4 *mid_geom, const float *mid_w, long long n_mid, hipStream_t st) {
-    TSP_REQUIRE(n_mid < (1ll << 28), TSP_EINVAL, "%lld mid footprints in one render block (kernel G indexes its work items with 32 bits)", n_mid);
-    if (MODE == TSP_MODE_RGB) return launch_mid_gather_kernel<MODE, 3, 16, TSP_G_OCC3>(ctx, ta, mid_geom, mid_w, n_mid, st);
-    if (second_channel) return launch_mid_gather_kernel<MODE, 2, 16, TSP_G_OCC2>(ctx, ta, mid_geom, mid_w, n_mid, st);
-    return launch_mid_gather_kernel<MODE, 1, TSP_G_HR1, TSP_G_OCC1>(ctx, ta, mid_geom, mid_w, n_mid, st);
+    TSP_REQUIRE(n_mid < (1ll << 28), TSP_EINVAL, "%lld mid footprints in one launch (kernel G indexes its work items with 32 bits; run_pipeline slices the list)", n_mid);
+    // the mid list is drawn in two passes over it: footprints below mid_narrow_px by kernel N (four records per wave step on
+    // 16-column strips), the rest by kernel G (one record per wave step on 64-column strips); 0 = everything by kernel G
+    const float split = ctx->mid_narrow_px;
+    int rc;
+    if (split > 0.0f) {
+        if (MODE == TSP_MODE_RGB) rc = launch_narrow_gather_kernel<MODE, 3, 16, TSP_G_OCC3>(ctx, ta, mid_geom, mid_w, n_mid, split, st);
+        else if (second_channel) rc = launch_narrow_gather_kernel<MODE, 2, 16, TSP_G_OCC2>(ctx, ta, mid_geom, mid_w, n_mid, split, st);
+        else rc = launch_narrow_gather_kernel<MODE, 1, TSP_G_HR1, TSP_G_OCC1>(ctx, ta, mid_geom, mid_w, n_mid, split, st);
+        if (rc) return rc;
+    }
+    if (MODE == TSP_MODE_RGB) return launch_mid_gather_kernel<MODE, 3, 16, TSP_G_OCC3>(ctx, ta, mid_geom, mid_w, n_mid, split, st);
+    if (second_channel) return launch_mid_gather_kernel<MODE, 2, 16, TSP_G_OCC2>(ctx, ta, mid_geom, mid_w, n_mid, split, st);
+    return launch_mid_gather_kernel<MODE, 1, TSP_G_HR1, TSP_G_OCC1>(ctx, ta, mid_geom, mid_w, n_mid, split, st);
 }
 
 int launch_mid_gather(tsp_context *ctx, TileArgs ta, int mode, bool second_channel, const float4 *mid_geom, const float *mid_w,

@@ -60,7 +60,7 @@ struct Record4 {   // rgb variant (24 B)
 };
 
 struct Counters {      // device-side, zeroed per render call
-    unsigned long long n_small, n_mid, n_huge, n_culled, n_fragments, huge_count, next_chunk, pad1;     // next_chunk: kernel S's batch counter
+    unsigned long long n_small, n_mid, n_huge, n_culled, n_fragments, huge_count, next_chunk, mid_odd_weights;     // next_chunk: kernel S's batch counter; mid_odd_weights: the mid list holds a weight that is not finite (kernel N's fill pass)
     unsigned long long n_frag_class[4];   // n_fragments by the kernel that drew them: S, G, H2, (unused)
 };
 
@@ -138,6 +138,7 @@ struct tsp_context {
     int stream_blocks_per_cu = 0;    // kernel S: persistent workgroups per CU (0 = what the occupancy query reports)
     int debug_gather_full_lut = 0;   // kernel G: 1 = the whole mip pyramid in LDS even when the kernel image is symmetric (measurement aid)
     double mid_item_scale = 0.35;    // kernel G: records per work item = this x sqrt(records), rounded to a power of two (option mid_item_scale_milli)
+    float mid_narrow_px = 64.0f;     // mid footprints narrower than this are drawn by kernel N, four records per wave step (0: all by kernel G; option mid_narrow_px_milli)
     int mid_item_records = 0;        // kernel G: records per work item (0 = by list length; a power of two from 64 to 1024)
     int stream_batch_chunks = 8;     // kernel S: the largest batch of consecutive chunks a workgroup takes from the shared counter
     bool chunk_cull = true;           // chunks (512 consecutive particles) whose bounds lie outside the view are skipped by kernel S
