@@ -623,8 +623,9 @@ def test_asymmetric_kernel_lut_uses_full_tables(native, mips):
 
 @pytest.mark.parametrize("mode", ["density", "weighted", "rgb", "depth"])
 def test_mid_footprints_gather(native, mips, mode):
-    """The footprints below 64 px that kernel S defers are drawn by kernel G (register gather over tile bins of the records):
-    against the oracle, exact fragment count included, for every work-item size, with more than 2048 footprints per wave strip
+    """The footprints below 64 px that kernel S defers are drawn by kernel N (four records per wave step on 16-column strips)
+    and / or kernel G (one record per wave step on 64-column strips), split by option mid_narrow_px_milli (64000 = all by N, the
+    default; 0 = all by G; 24000 = both): against the oracle, exact fragment count included, for every work-item size, with more than 2048 footprints per wave strip
     (float32 accumulators folded into the float64 target), R = 300 (partial last tiles) and widths on the class boundaries and
     on every mip-level threshold."""
     from oracle import oracle_np
@@ -657,8 +658,9 @@ def test_mid_footprints_gather(native, mips, mode):
         want, nfrag = oracle_render(pos, h, m, q if mode == "weighted" else None, None, 0, M, sf, R, mips)
         md = native.MODE_WEIGHTED
     ctx.set_option("p_small_milli", 0)         # everything below 64 px goes to the mid list
-    for variant, items in ((1, 0), (1, 64), (1, 8192)):
+    for variant, items in ((64000, 0), (64000, 64), (64000, 8192), (0, 0), (0, 64), (0, 8192), (24000, 0), (45254, 256)):
         for count in (1, 0):
+            ctx.set_option("mid_narrow_px_milli", variant)
             ctx.set_option("mid_item_records", items); ctx.set_option("count_fragments", count)
             ctx.render(M, sf, mode=md)
             got = ctx.read_image()
@@ -676,3 +678,56 @@ def test_mid_footprints_gather(native, mips, mode):
             if count:
                 assert st["n_fragments"] == nfrag, (variant, items)
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["weighted", "rgb"])
+def test_mid_footprints_with_weights_that_are_not_finite(native, mips, mode):
+    """Kernel N draws four records per wave step and lets a slot read zeros in the pixel rows its record does not cover:
+    "0 x weight" must not become NaN there when a weight is infinite or NaN.  The fill pass flags such a list and the kernel
+    then draws slot by slot.  Pixels the odd particles do not cover must equal the render without them; the pixels they cover
+    are not finite in either kernel (inf x k, or NaN where k = 0), as in the generic kernel."""
+    from oracle import oracle_np
+    R, scale, n = 256, 100.0, 8000
+    M, sf = oracle_np.transform_matrix(np.eye(3), np.zeros(3), scale)
+    rs = np.random.RandomState(41)
+    pos = np.zeros((n, 3), dtype=np.float32)
+    pos[:, :2] = rs.uniform(-1.0, 1.0, size=(n, 2)) * scale
+    P = np.exp(rs.uniform(np.log(17.0), np.log(60.0), n))
+    h = (P * scale / (2.0 * R)).astype(np.float32)
+    m = rs.uniform(0.5, 2.0, n).astype(np.float32)
+    rgb = rs.uniform(0.1, 1.0, size=(n, 3)).astype(np.float32)
+    odd = np.arange(0, n, 400)                       # 20 odd particles spread over the image
+    m_odd, rgb_odd = m.copy(), rgb.copy()
+    m_odd[odd[::2]] = np.inf; m_odd[odd[1::2]] = np.nan
+    rgb_odd[odd[::2], 1] = np.inf; rgb_odd[odd[1::2], 2] = np.nan
+    keep = np.ones(n, dtype=bool); keep[odd] = False
+    md = native.MODE_RGB if mode == "rgb" else native.MODE_WEIGHTED
+    images = {}
+    for label, sel, mm, cc in (("clean", keep, m, rgb), ("odd", np.ones(n, dtype=bool), m_odd, rgb_odd)):
+        for split in (64000, 0):
+            ctx = native.Context(R, 4 if mode == "rgb" else 2)
+            ctx.set_kernel_mips(mips)
+            ctx.set_option("mid_narrow_px_milli", split)
+            ctx.upload_particles(pos[sel, 0], pos[sel, 1], pos[sel, 2], h[sel], None if mode == "rgb" else mm[sel])
+            if mode == "rgb":
+                ctx.upload_rgb(cc[sel, 0].copy(), cc[sel, 1].copy(), cc[sel, 2].copy())
+            ctx.render(M, sf, mode=md)
+            assert ctx.stats()["n_mid"] == int(sel.sum())
+            images[(label, split)] = ctx.read_image().astype(np.float64)
+            ctx.close()
+    clean = images[("clean", 64000)]
+    nch = 3 if mode == "rgb" else 1
+    for split in (64000, 0):
+        got = images[("odd", split)]
+        finite = np.isfinite(got[..., :nch]).all(axis=-1)
+        # pixels no odd footprint square reaches: exactly the clean render's sums (same records, same order of accumulation classes)
+        half = (P[odd] / 2.0)[:, None]
+        px = np.arange(R) + 0.5
+        pcx = (pos[odd, 0] / scale + 1.0) * R / 2.0; pcy = (1.0 - pos[odd, 1] / scale) * R / 2.0
+        cx = np.abs(px[None, :] - pcx[:, None]) < half + 1e-3; cy = np.abs(px[None, :] - pcy[:, None]) < half + 1e-3
+        touched = np.einsum("ky,kx->yx", cy.astype(np.int64), cx.astype(np.int64)) > 0
+        assert finite[~touched].all(), "a pixel outside every odd footprint is not finite"
+        assert np.allclose(got[~touched][:, :nch], clean[~touched][:, :nch], rtol=1e-5, atol=0), split
+        assert (~finite).sum() > 0
+    # (which of the TOUCHED pixels are finite may differ between the kernels: both skip the strips that lie outside the disc inscribed
+    # in a footprint square -- where the kernel value is exactly 0 and "0 x inf" would be NaN -- and their strips differ in shape)
