@@ -51,8 +51,8 @@ VALU_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32 vector peak (256 CUs 
 # = 2 FMAs once the x-interpolated texel rows exist; nearest (kernels S / M) one multiply-add of the texel into the pixel
 FMAS_PER_FRAGMENT = {"stream": 1, "mid": 1, "huge": 2}
 B_ALG = {"density": 20, "weighted": 24, "rgb": 28}     # algorithmic bytes/particle
-KERNELS = ("stream", "mid", "huge")        # tsp_stats names of kernels S, G, H2
-KERNEL_SYMBOL = {"stream": "splat_stream_kernel", "mid": "splat_mid_gather_kernel", "huge": "splat_huge2_kernel"}
+KERNELS = ("stream", "mid", "huge")        # tsp_stats names of kernels S, N (the mid footprints; kernel G when option mid_narrow_px_milli = 0), H2
+KERNEL_SYMBOL = {"stream": "splat_stream_kernel", "mid": "splat_narrow_gather_kernel", "huge": "splat_huge2_kernel"}
 # one ncclReduce of the R^2 x C float32 image onto the root over xGMI (ring: 7 steps of 1/8 of the image per link, ~153 GB/s per
 # link and ~20 us per step): an ESTIMATE -- no multi-GPU box was available to this build -- used only by `projected_speedup_1to8`
 REDUCE_ESTIMATE_MS = 0.3
@@ -337,7 +337,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload_name, "total_particles": n_total,
                    "particles_per_gpu": n_per, "resolution": R, "sharding": f"index-range x{world}",
-                   "pipeline": "generic" if args.generic else "three-class (stream S / strip-binned gather G / row-uniform gather H2)",
+                   "pipeline": "generic" if args.generic else "three-class (stream S / four-records-per-wave strip gather N / row-uniform gather H2)",
                    "fragments_per_particle": frags / n_drawn, "frames_per_s": 1e3 / ms_per_step},
         "ms_per_step_median": ms_median, "value_at_median": n_drawn / (ms_median * 1e-3),
         "fragments_per_s": frags / (ms_per_step * 1e-3),
