@@ -414,6 +414,9 @@ def main():
         result["visualizer_export_frame"] = visualizer_lines(local_rank, R, args, whole_ms, n_total if (n_total == 10**9 and not weak) else None)
         result["interactive_frame"] = interactive_line(local_rank, R, args)
         result["interactive_frame_zoomed"] = interactive_line(local_rank, R, args, zoom=20.0)
+        # the smallest block the progressive renderer can draw is one stratum of the load-time order (<= 3.2e7 particles, 1/8 of a
+        # snapshot up to 2.5e8): the largest such snapshot at the fragment-heaviest camera measured (scale 50: 2500 fragments / particle)
+        result["interactive_frame_zoomed_2p5e8_scale50"] = interactive_line(local_rank, R, args, n=250_000_000, frames=16, zoom=50.0)
     if not args.no_cpu_baseline and not args.headline_only and world == 1 and not args.as_shard:      # reported baseline: rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(args, n_total, M, sf, R)
     print(json.dumps(result), flush=True)
