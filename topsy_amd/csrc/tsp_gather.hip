@@ -1177,6 +1177,7 @@ static int launch_mid_gather_mode(tsp_context *ctx, TileArgs ta, bool second_cha
         else if (second_channel) rc = launch_narrow_gather_kernel<MODE, 2, 16, TSP_G_OCC2>(ctx, ta, mid_geom, mid_w, n_mid, split, st);
         else rc = launch_narrow_gather_kernel<MODE, 1, TSP_G_HR1, TSP_G_OCC1>(ctx, ta, mid_geom, mid_w, n_mid, split, st);
         if (rc) return rc;
+        if (split >= P_BILINEAR) return TSP_OK;        // (every mid footprint is below 64 px: nothing is left for kernel G)
     }
     if (MODE == TSP_MODE_RGB) return launch_mid_gather_kernel<MODE, 3, 16, TSP_G_OCC3>(ctx, ta, mid_geom, mid_w, n_mid, split, st);
     if (second_channel) return launch_mid_gather_kernel<MODE, 2, 16, TSP_G_OCC2>(ctx, ta, mid_geom, mid_w, n_mid, split, st);
