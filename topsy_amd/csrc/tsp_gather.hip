@@ -740,7 +740,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_narrow_gather_kernel(TileArgs 
             int roq[2];
             roq[0] = rt_quad[0];
 #define TSP_N_ROW(K, T_)                                                                                        \
-            if ((covmask >> (4 * (K) + (T_))) & 1) {                                                            \
+            if (__builtin_expect((covmask >> (4 * (K) + (T_))) & 1, 1)) {      /* (likely: the FMA stays in line) */ \
                 _Pragma("unroll") for (int c = 0; c < NACC; ++c) fmac_plain(acc[4 * (K) + (T_)][c], kv[T_], wl[c]); \
             }
 #define TSP_N_GROUP(K)                                                                                          \
