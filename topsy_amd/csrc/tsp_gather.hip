@@ -167,12 +167,59 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
         since_fold += __popcll(hits);
         const float g_invP = 1.0f / g.z;
         const float g_w1 = (MODE == TSP_MODE_RGB) ? gw1 : g.w * gw1;
+        // The rows of NH = 64 / HR hits are evaluated in ONE pass: lane j works out pixel row j % HR for hit j / HR (with HR = 32 the
+        // upper half of the wave used to repeat the lower half's work); the hits' parameters reach their lanes through ds_bpermute
+        // (the LDS crossbar, not the vector ALU) instead of a v_readlane each per hit.  Columns and the row walk follow hit by hit.
+        constexpr int NH = 64 / HR;
         while (hits) {
-            const int src = __ffsll((long long)hits) - 1;
-            hits &= hits - 1;
+            int srcs[NH], n_h = 0;
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                srcs[i] = i ? srcs[0] : 0;
+                if (hits) { srcs[i] = __ffsll((long long)hits) - 1; hits &= hits - 1; n_h = i + 1; }
+            }
+            // ---- rows: lane j evaluates row j % HR of hit j / HR and the texel row of the row above it -----------------
+            unsigned long long cov64, chg64, jmp64;
+            int r512;                                   // byte offset of this lane's texel row in PT
+            {
+                int src_l = srcs[0];
+#pragma unroll
+                for (int i = 1; i < NH; ++i) src_l = (lane >= HR * i) ? srcs[i] : src_l;
+                const int bp = src_l << 2;
+                const float pcy_l = __int_as_float(__builtin_amdgcn_ds_bpermute(bp, __float_as_int(g.y)));
+                const float half_l = __int_as_float(__builtin_amdgcn_ds_bpermute(bp, __float_as_int(g_half)));
+                const float invP_l = __int_as_float(__builtin_amdgcn_ds_bpermute(bp, __float_as_int(g_invP)));
+                const float d = pyc_own - pcy_l;
+                const float cv = (__builtin_fabsf(d) < half_l) ? 1.0f : 0.0f;
+                // the canonical float32 texel coordinate (tsp_math.h: the oracle forms it with the same operations -- a value next to
+                // a zero texel is proportional to its fraction, so even one ulp of difference here shows at 1e-5 relative)
+                const float v = (d + half_l) * invP_l;
+                const float tv = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, 64.0f, -0.5f), 0.0f, 63.0f);
+                const float fr = __builtin_amdgcn_fractf(tv) * cv;      // (tv - floor(tv), exact for 0 <= tv <= 63, in one instruction)
+                const int r = (int)tv;                  // (tv >= 0: the conversion truncates = floor)
+                // texel row of the pixel row above = the value of the lane before (v_mov_b32_dpp wave_shr:1); row 0 of every hit
+                // is excluded below
+                const int rprev = __builtin_amdgcn_mov_dpp(r, 0x138, 0xf, 0xf, false);
+                r512 = __mul24(r, PT_STRIDE * 4);      // (v_mul_u32_u24: full rate; v_mul_lo_u32 takes four issue slots)
+                asm volatile("" ::: "memory");          // (in-order LDS: the previous footprints' table reads are done)
+                rt[lane] = make_float2(fr, cv - fr);      // (the table has 64 slots per wave: HR rows for each of the NH hits)
+                asm volatile("" ::: "memory");
+                // the row masks straight from vector compares (as __ballot(bool expression) each costs a v_cndmask + v_cmp round trip)
+                constexpr unsigned long long ROW0S = (HR == 64) ? 1ull : ((HR == 32) ? 0x0000000100000001ull : 0x0001000100010001ull);
+                cov64 = __builtin_amdgcn_fcmpf(__builtin_fabsf(d), half_l, 4 /* FCMP_OLT */);
+                chg64 = __builtin_amdgcn_uicmp((unsigned)r, (unsigned)rprev, 33 /* ICMP_NE */) & cov64 & ~ROW0S;
+                // texel rows advance by at most one per pixel row when P >= 64; rounding at P ~ 64 may still skip one
+                jmp64 = __builtin_amdgcn_uicmp((unsigned)r, (unsigned)(rprev + 1), 33 /* ICMP_NE */) & chg64;
+            }
+            for (int hh = 0; hh < n_h; ++hh) {
+            int src = srcs[0];
+#pragma unroll
+            for (int i = 1; i < NH; ++i) src = (hh == i) ? srcs[i] : src;
+            constexpr unsigned long long ROWS = (HR == 64) ? ~0ull : ((1ull << (HR & 63)) - 1ull);      // (the bits above belong to the next hit)
+            mask_t covmask = (mask_t)((cov64 >> ((HR * hh) & 63)) & ROWS), chgmask = (mask_t)((chg64 >> ((HR * hh) & 63)) & ROWS),
+                   jmpmask = (mask_t)((jmp64 >> ((HR * hh) & 63)) & ROWS);
             // the footprint's parameters, wave-uniform (scalar registers)
             const float pcx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.x), src));
-            const float pcy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.y), src));
             const float half = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_half), src));
             const float invP = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g_invP), src));
             float4 wq;
@@ -187,34 +234,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
                 asm volatile("v_mov_b32 %0, %1" : "=v"(wq.y) : "s"(wq.y));
                 if (NACC >= 3) asm volatile("v_mov_b32 %0, %1" : "=v"(wq.z) : "s"(wq.z));
             }
-            // ---- rows: lane j < HR evaluates row j and the texel row of the row above it -----------------
-            mask_t covmask, chgmask, jmpmask;
-            int r512;                                   // byte offset of this lane's texel row in PT
-            {
-                const float d = pyc_own - pcy;
-                const float cv = (__builtin_fabsf(d) < half) ? 1.0f : 0.0f;
-                // the canonical float32 texel coordinate (tsp_math.h: the oracle forms it with the same operations -- a value next to
-                // a zero texel is proportional to its fraction, so even one ulp of difference here shows at 1e-5 relative)
-                const float v = (d + half) * invP;
-                const float tv = __builtin_amdgcn_fmed3f(__builtin_fmaf(v, 64.0f, -0.5f), 0.0f, 63.0f);
-                const float fr = __builtin_amdgcn_fractf(tv) * cv;      // (tv - floor(tv), exact for 0 <= tv <= 63, in one instruction)
-                const int r = (int)tv;                  // (tv >= 0: the conversion truncates = floor)
-                // texel row of the pixel row above = the value of the lane before (v_mov_b32_dpp wave_shr:1); lane 0 and
-                // row 0 of the second half are excluded by `myrow > 0` below
-                const int rprev = __builtin_amdgcn_mov_dpp(r, 0x138, 0xf, 0xf, false);
-                r512 = __mul24(r, PT_STRIDE * 4);      // (v_mul_u32_u24: full rate; v_mul_lo_u32 takes four issue slots)
-                asm volatile("" ::: "memory");          // (in-order LDS: the previous footprint's table reads are done)
-                rt[lane] = make_float2(fr, cv - fr);      // (every lane writes: the table has 64 slots per wave, the rows sit in the first HR)
-                asm volatile("" ::: "memory");
-                // the row masks straight from vector compares (as __ballot(bool expression) each costs a v_cndmask + v_cmp round trip);
-                // the lanes that hold rows, and row 0 of the strip, are constants
-                constexpr unsigned long long ROWS = (HR == 64) ? ~0ull : ((1ull << (HR & 63)) - 1ull);
-                const unsigned long long cov64 = __builtin_amdgcn_fcmpf(__builtin_fabsf(d), half, 4 /* FCMP_OLT */) & ROWS;
-                const unsigned long long chg64 = __builtin_amdgcn_uicmp((unsigned)r, (unsigned)rprev, 33 /* ICMP_NE */) & cov64 & ~1ull;
-                // texel rows advance by at most one per pixel row when P >= 64; rounding at P ~ 64 may still skip one
-                const unsigned long long jmp64 = __builtin_amdgcn_uicmp((unsigned)r, (unsigned)(rprev + 1), 33 /* ICMP_NE */) & chg64;
-                covmask = (mask_t)cov64; chgmask = (mask_t)chg64; jmpmask = (mask_t)jmp64;
-            }
+            const float2 *rt_quad_h = rt_quad + HR * hh;      // this hit's rows of the table
             if (covmask == 0) continue;
             // the first covered row's texel rows are loaded before the row walk (below): it is never a "change"
             const mask_t first = covmask & ((mask_t)0 - covmask);
@@ -225,10 +245,10 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             constexpr bool JIT = (HR >= 32);
             constexpr int NRF = JIT ? 2 : NG;
             float2 rowf[NRF];
-            if constexpr (JIT) rowf[0] = rt_quad[0];
+            if constexpr (JIT) rowf[0] = rt_quad_h[0];
             else {
 #pragma unroll
-                for (int k = 0; k < NG; ++k) rowf[k] = rt_quad[4 * k];
+                for (int k = 0; k < NG; ++k) rowf[k] = rt_quad_h[4 * k];
             }
             // ---- columns: W per lane ----
             int caddr[W];
@@ -257,7 +277,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             };
             auto lerp = [&](int w, float2 t) -> float { return __builtin_fmaf(t.y, fxs[w], t.x * gxs[w]); };
             // texel rows of the first covered pixel row (wave-uniform byte offset of its texel row in PT), the pair after them in flight
-            int r_off = __builtin_amdgcn_readlane(r512, (HR == 64 ? __ffsll((long long)covmask) : __ffs((int)covmask)) - 1);
+            int r_off = __builtin_amdgcn_readlane(r512, (HR == 64 ? __ffsll((long long)covmask) : __ffs((int)covmask)) - 1 + HR * hh);
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 top[w] = lerp(w, pair_at(w, r_off)); bot[w] = lerp(w, pair_at(w, r_off + PT_STRIDE * 4));
@@ -318,7 +338,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
             // footprint's set-up at the control-flow merges: 32.7 -> 49 ms at 1e9 particles.  One code path per row it stays.)
 #define TSP_H2_GROUP(K)                                                                                        \
             if constexpr ((K) < NG) {                                                                          \
-                if constexpr (JIT && (K) + 1 < NG) rowf[((K) + 1) & 1] = rt_quad[4 * ((K) + 1)];               \
+                if constexpr (JIT && (K) + 1 < NG) rowf[((K) + 1) & 1] = rt_quad_h[4 * ((K) + 1)];               \
                 if (((covmask >> (4 * (K))) & 15) != 0) {                                                    \
                     if constexpr (JIT) asm volatile("" : "+v"(rowf[(K) & 1].x), "+v"(rowf[(K) & 1].y));        \
                     TSP_H2_ROW(K, 0) TSP_H2_ROW(K, 1) TSP_H2_ROW(K, 2) TSP_H2_ROW(K, 3)                          \
@@ -340,6 +360,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
                 atomicAdd(&a.cnt->n_frag_class[3], (unsigned long long)__popcll((unsigned long long)chgmask) + (groups << 32));
             }
 #endif
+            }      // (hits of this row pass)
         }
     }
     // ---- add this wave's partial strip into the render target ---------------------------------------
