@@ -677,7 +677,7 @@ __global__ __launch_bounds__(H2T, OCC) void splat_narrow_gather_kernel(TileArgs 
     if (idle_wave) return;
 
     const size_t first = (size_t)a.hband_base[strip] + (size_t)chunk * a.item_records;
-    constexpr int NWN = NW + 1;           // weights per record of kernel N's bins: (w0, w1[, w2]); the geometry carries 1 / P in their place
+    constexpr int NWN = 2 * NW;           // weight floats per record of kernel N's bins: (w0, w1) / (w0, w1, w2, -): one 8- / 16-byte element; the geometry carries 1 / P
     const float4 *geom = a.geom + first;
     const float *wts = a.w + first * NWN;
     const unsigned n_rec = (unsigned)min(a.item_records, a.hband_count[strip] - chunk * a.item_records);
@@ -687,10 +687,10 @@ __global__ __launch_bounds__(H2T, OCC) void splat_narrow_gather_kernel(TileArgs 
         const unsigned ri = min(r0 + slot, n_rec - 1u);
         // (32-bit byte offsets from the item's first record -- an item holds <= 8192 records: one scalar base + one vector offset per load)
         g = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(geom) + (ri << 4));
-        const float *wp = reinterpret_cast<const float *>(reinterpret_cast<const char *>(wts) + ri * (NWN * 4u));
-        gw0 = wp[0];
-        gw1 = (NACC >= 2) ? wp[1] : 0.0f;
-        gw2 = (NACC >= 3) ? wp[2] : 0.0f;
+        const char *wp = reinterpret_cast<const char *>(wts) + ri * (NWN * 4u);
+        if (NW == 2) { const float4 q = *reinterpret_cast<const float4 *>(wp); gw0 = q.x; gw1 = q.y; gw2 = q.z; }
+        else if (NACC >= 2) { const float2 q = *reinterpret_cast<const float2 *>(wp); gw0 = q.x; gw1 = q.y; gw2 = 0.0f; }
+        else { gw0 = *reinterpret_cast<const float *>(wp); gw1 = gw2 = 0.0f; }
     };
     const int n_pass = a.cnt->mid_odd_weights ? 4 : 1;
     float4 g_next; float gw0_next, gw1_next, gw2_next;
@@ -1066,9 +1066,9 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict
                 const long long slot = tile_base[t] + (lds ? s_base[t] + atomicAdd(&s_cnt[t], 1) : atomicAdd(&tile_cursor[t], 1));
                 if (b.narrow) {
                     out_geom[slot] = gn;
-                    out_w[slot * (NW + 1)] = g[k].w;
-                    out_w[slot * (NW + 1) + 1] = w0;
-                    if (NW == 2) out_w[slot * (NW + 1) + 2] = w1;
+                    // (the weights as ONE store: the fill pass is bound by the number of scattered stores, not by their bytes)
+                    if (NW == 2) reinterpret_cast<float4 *>(out_w)[slot] = make_float4(g[k].w, w0, w1, 0.0f);
+                    else reinterpret_cast<float2 *>(out_w)[slot] = make_float2(g[k].w, w0);
                 } else {
                     out_geom[slot] = g[k];
                     out_w[slot * NW] = w0;
@@ -1129,7 +1129,7 @@ static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geo
         ws.mband_capacity = std::max<int64_t>(ws.mband_capacity, total_records + total_records / 4 + 1024);
         ws.mitem_capacity = std::max<int64_t>(ws.mitem_capacity, (int64_t)total_items + total_items / 4 + 1024);
         TSP_HIP(hipMalloc(&ws.mband_geom, (size_t)ws.mband_capacity * sizeof(float4)));
-        TSP_HIP(hipMalloc(&ws.mband_w, (size_t)ws.mband_capacity * 3 * sizeof(float)));      // (kernel N keeps up to three weights per record here)
+        TSP_HIP(hipMalloc(&ws.mband_w, (size_t)ws.mband_capacity * 4 * sizeof(float)));      // (kernel N keeps a float2 / float4 of weights per record here)
         TSP_HIP(hipMalloc((void **)&ws.mitem_tile, (size_t)ws.mitem_capacity * sizeof(int)));
     }
     hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int *)ws.mband_count, n_tiles, ws.mband_base, ws.mitem_base, ws.mitem_tile, total_items, item_records);
