@@ -410,6 +410,9 @@ __global__ __launch_bounds__(H2T, OCC) void splat_huge2_kernel(TileArgs a) {
 #define TSP_G_OCC3 5
 #endif
 constexpr int GCHUNK_MAX = 1024;          // records per work item of kernel G (fewer for short lists: enough items to fill the device)
+#ifndef TSP_BIN_PER
+#define TSP_BIN_PER 4          // records per thread of the mid binning passes
+#endif
 constexpr int G_LDS_TILES = 16384;        // the binning passes keep their tile counters in LDS up to this many tiles (global atomics beyond): 128 KB in the fill pass
                                           // (kernel N's 16 x 16 strips at 2048^2; with global atomics its rgb binning took 20 ms instead of 1)
 
@@ -949,7 +952,7 @@ __device__ __forceinline__ bool strip_hit(const float4 g, int tx, int ty, const 
 }
 // pass 1: records per tile (counted in LDS first when the image has few enough tiles: one global atomic per workgroup and tile)
 __global__ __launch_bounds__(256) void tile_count_kernel(const float4 *__restrict__ geom, long long n, BinArgs b, int *__restrict__ tile_count) {
-    constexpr int PER = 4;
+    constexpr int PER = TSP_BIN_PER;
     extern __shared__ int s_tile[];
     const int tiles_x = b.tiles_x, n_tiles = tiles_x * b.tiles_y;
     const bool lds = n_tiles <= G_LDS_TILES;
@@ -1016,7 +1019,7 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict
                                                         float4 *__restrict__ out_geom, float *__restrict__ out_w,
                                                         const long long *__restrict__ tile_base, int *__restrict__ tile_cursor,
                                                         unsigned long long *__restrict__ odd_flag) {
-    constexpr int PER = 4;
+    constexpr int PER = TSP_BIN_PER;
     extern __shared__ int s_tile[];        // [n_tiles] counts, then [n_tiles] bases
     const int tiles_x = b.tiles_x, n_tiles = tiles_x * b.tiles_y;
     const bool lds = n_tiles <= G_LDS_TILES;
@@ -1111,7 +1114,7 @@ static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geo
         TSP_HIP(hipFuncSetAttribute((const void *)tile_fill_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_LDS_TILES * (int)sizeof(int)));
         ctx->kernel_attr_done |= 1u << (8 + NW);
     }
-    const unsigned grid = (unsigned)((n_mid + 1023) / 1024);
+    const unsigned grid = (unsigned)((n_mid + 256 * TSP_BIN_PER - 1) / (256 * TSP_BIN_PER));
     hipLaunchKernelGGL(tile_count_kernel, dim3(grid), dim3(256), lds ? n_tiles * sizeof(int) : 0, st, mid_geom, n_mid, ba, ws.mband_count);
     // the sizes of the bins are known on the device only: the prefix pass runs once without the item table to size it, the
     // host reads the two totals (one small copy; the pipeline already synchronises once per frame for the record counts) and grows
