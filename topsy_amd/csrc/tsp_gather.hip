@@ -1,9 +1,12 @@
-// tsp_gather.hip -- the tile-gather kernel of the splat pipeline (footprints >= 64 px, bilinear sampling on mip 0), gfx950.
+// tsp_gather.hip -- the strip-gather kernels of the splat pipeline, gfx950: the footprints kernel S defers (tsp_pipeline.hip).
 //
-// What it computes is fragment_* + additive blend of the reference for its magnified footprints
-// (src/topsy/shaders/sph.wgsl:139-165, sampler src/topsy/sph.py:425-426) in the arithmetic of tsp_math.h; the records it
-// consumes (pixel-space centre, width, weights) are written by kernel S (tsp_pipeline.hip).
-//   kernel H2  splat_huge2_kernel  row-uniform gather: every footprint >= 64 px, every mode
+// What they compute is fragment_* + additive blend of the reference (src/topsy/shaders/sph.wgsl:139-165, sampler
+// src/topsy/sph.py:425-426) in the arithmetic of tsp_math.h; the records they consume (pixel-space centre, width, weights) are
+// written by kernel S.  A wave owns a strip of the image, its accumulators sit in registers:
+//   kernel H2  splat_huge2_kernel          row-uniform gather: every footprint >= 64 px (bilinear on mip 0), every mode
+//   kernel N   splat_narrow_gather_kernel  the mid footprints (16-64 px, nearest on mips 0-3), four records per wave step (round 6)
+//   kernel G   splat_mid_gather_kernel     round 5's mid kernel, one record per wave step (option mid_narrow_px_milli < 64000)
+//   + the binning passes: huge_band_fill_kernel (H2), tile_count / tile_prefix / tile_fill_kernel (N, G)
 // (Rounds 1-4 also carried the per-pixel gather kernel H, the matrix-core kernels H3 / H4 and the option kernel I: none was
 // selected by a default rule -- f32 MFMA has no peak advantage over the VALU on gfx950 and H2 issues half the flop; kernel I is
 // exact only to ~1e-6 of a footprint's peak -- so round 5 removed them; HISTORY.md keeps their designs and measurements.)
