@@ -12,6 +12,10 @@ library's own generic kernel) wherever the oracle finishes in seconds on the GPU
   configs[4]  rgb, 2048^2, 5e6 star particles ........................... vs oracle: colour channels 1e-5, count channel and
                                                                          fragment count exact
 
+What does NOT meet the oracle at full size: configs[2] at exactly 1e8 particles (mass / shard-additivity properties) and
+configs[4] at 5e7 particles (against the library's own generic kernel) -- tests/test_gpu_scale.py; the oracle sees those
+configurations at the sizes listed above.
+
 Tolerances: the reference's own tests (tests/test_render_output.py:161-241) allow atol 1.5e-7 on a weighted image whose
 values are ~1e-5 (1.5e-2 relative) and ~1 % statistical agreement on the density image; north_star asks 1e-5 relative on the
 float buffer, which is what is asserted here.
