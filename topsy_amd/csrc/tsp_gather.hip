@@ -416,6 +416,7 @@ constexpr int GCHUNK_MAX = 1024;          // records per work item of kernel G (
 #ifndef TSP_BIN_PER
 #define TSP_BIN_PER 4          // records per thread of the mid binning passes
 #endif
+constexpr int G_WIN_TILES = 4096;         // strips per LDS window of the binning passes (a window = whole rows of strips)
 constexpr int G_LDS_TILES = 16384;        // the binning passes keep their tile counters in LDS up to this many tiles (global atomics beyond): 128 KB in the fill pass
                                           // (kernel N's 16 x 16 strips at 2048^2; with global atomics its rgb binning took 20 ms instead of 1)
 
@@ -929,6 +930,10 @@ struct BinArgs {
     float disc_k2;             // as TileArgs::disc_k2 (0: the square alone decides)
     int exact;
     int narrow;                // kernel N's record layout: geometry (pcx, pcy, P, 1 / P), weights (w0, w1[, w2]) -- see tile_fill_kernel
+    // The passes keep their per-strip counters in LDS, a WINDOW of win_rows rows of strips at a time (blockIdx.y = window): every
+    // workgroup reads its records once per window and handles the pairs whose strip lies in it.  One window while the image has
+    // <= 4096 strips; 16384 strips (16 x 16-px strips at 2048^2) in one window left one workgroup per CU (128 KB of LDS)
+    int win_rows;
 };
 __device__ __forceinline__ TileSpan tile_span(const float4 g, const BinArgs &b) {
     TileSpan s; s.x0 = s.y0 = 1; s.x1 = s.y1 = 0;
@@ -957,27 +962,28 @@ __device__ __forceinline__ bool strip_hit(const float4 g, int tx, int ty, const 
 __global__ __launch_bounds__(256) void tile_count_kernel(const float4 *__restrict__ geom, long long n, BinArgs b, int *__restrict__ tile_count) {
     constexpr int PER = TSP_BIN_PER;
     extern __shared__ int s_tile[];
-    const int tiles_x = b.tiles_x, n_tiles = tiles_x * b.tiles_y;
-    const bool lds = n_tiles <= G_LDS_TILES;
+    const int tiles_x = b.tiles_x;
+    const int row0 = (int)blockIdx.y * b.win_rows, row1 = min(b.tiles_y, row0 + b.win_rows) - 1, t0 = row0 * tiles_x, n_win = (row1 - row0 + 1) * tiles_x;
+    const bool lds = n_win <= G_LDS_TILES;
     if (lds) {
-        for (int t = threadIdx.x; t < n_tiles; t += 256) s_tile[t] = 0;
+        for (int t = threadIdx.x; t < n_win; t += 256) s_tile[t] = 0;
         __syncthreads();
     }
-    int *cnt = lds ? s_tile : tile_count;
+    int *cnt = lds ? s_tile : tile_count + t0;
     const long long first = ((long long)blockIdx.x * 256 + threadIdx.x) * PER;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         if (first + k >= n) continue;
         const float4 g = geom[first + k];
         const TileSpan sp = tile_span(g, b);
-        for (int ty = sp.y0; ty <= sp.y1; ++ty)
+        for (int ty = max(sp.y0, row0); ty <= min(sp.y1, row1); ++ty)
             for (int tx = sp.x0; tx <= sp.x1; ++tx)
-                if (strip_hit(g, tx, ty, b)) atomicAdd(&cnt[ty * tiles_x + tx], 1);
+                if (strip_hit(g, tx, ty, b)) atomicAdd(&cnt[ty * tiles_x + tx - t0], 1);
     }
     if (lds) {
         __syncthreads();
-        for (int t = threadIdx.x; t < n_tiles; t += 256)
-            if (s_tile[t]) atomicAdd(&tile_count[t], s_tile[t]);
+        for (int t = threadIdx.x; t < n_win; t += 256)
+            if (s_tile[t]) atomicAdd(&tile_count[t0 + t], s_tile[t]);
     }
 }
 // between the passes (one workgroup): first record of every bin, first work item of every tile, the item -> tile table
@@ -1023,12 +1029,13 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict
                                                         const long long *__restrict__ tile_base, int *__restrict__ tile_cursor,
                                                         unsigned long long *__restrict__ odd_flag) {
     constexpr int PER = TSP_BIN_PER;
-    extern __shared__ int s_tile[];        // [n_tiles] counts, then [n_tiles] bases
-    const int tiles_x = b.tiles_x, n_tiles = tiles_x * b.tiles_y;
-    const bool lds = n_tiles <= G_LDS_TILES;
-    int *s_cnt = s_tile, *s_base = s_tile + n_tiles;
+    extern __shared__ int s_tile[];        // [strips of the window] counts, then as many bases
+    const int tiles_x = b.tiles_x;
+    const int row0 = (int)blockIdx.y * b.win_rows, row1 = min(b.tiles_y, row0 + b.win_rows) - 1, t0 = row0 * tiles_x, n_win = (row1 - row0 + 1) * tiles_x;
+    const bool lds = n_win <= G_LDS_TILES;
+    int *s_cnt = s_tile, *s_base = s_tile + n_win;
     if (lds) {
-        for (int t = threadIdx.x; t < n_tiles; t += 256) s_cnt[t] = 0;
+        for (int t = threadIdx.x; t < n_win; t += 256) s_cnt[t] = 0;
         __syncthreads();
     }
     const long long first = ((long long)blockIdx.x * 256 + threadIdx.x) * PER;
@@ -1040,17 +1047,18 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict
         if (first + k < n) {
             g[k] = geom[first + k];
             sp[k] = tile_span(g[k], b);
+            sp[k].y0 = max(sp[k].y0, row0); sp[k].y1 = min(sp[k].y1, row1);      // (the rows of this window)
             if (lds)
                 for (int ty = sp[k].y0; ty <= sp[k].y1; ++ty)
                     for (int tx = sp[k].x0; tx <= sp[k].x1; ++tx)
-                        if (strip_hit(g[k], tx, ty, b)) atomicAdd(&s_cnt[ty * tiles_x + tx], 1);
+                        if (strip_hit(g[k], tx, ty, b)) atomicAdd(&s_cnt[ty * tiles_x + tx - t0], 1);
         }
     }
     if (lds) {
         __syncthreads();
-        for (int t = threadIdx.x; t < n_tiles; t += 256) {
+        for (int t = threadIdx.x; t < n_win; t += 256) {
             const int c = s_cnt[t];
-            s_base[t] = c ? atomicAdd(&tile_cursor[t], c) : 0;
+            s_base[t] = c ? atomicAdd(&tile_cursor[t0 + t], c) : 0;
             s_cnt[t] = 0;
         }
         __syncthreads();
@@ -1069,10 +1077,10 @@ __global__ __launch_bounds__(256) void tile_fill_kernel(const float4 *__restrict
             for (int tx = sp[k].x0; tx <= sp[k].x1; ++tx) {
                 if (!strip_hit(g[k], tx, ty, b)) continue;
                 const int t = ty * tiles_x + tx;
-                const long long slot = tile_base[t] + (lds ? s_base[t] + atomicAdd(&s_cnt[t], 1) : atomicAdd(&tile_cursor[t], 1));
+                const long long slot = tile_base[t] + (lds ? s_base[t - t0] + atomicAdd(&s_cnt[t - t0], 1) : atomicAdd(&tile_cursor[t], 1));
                 if (b.narrow) {
                     out_geom[slot] = gn;
-                    // (the weights as ONE store: the fill pass is bound by the number of scattered stores, not by their bytes)
+                    // (the weights as ONE store)
                     if (NW == 2) reinterpret_cast<float4 *>(out_w)[slot] = make_float4(g[k].w, w0, w1, 0.0f);
                     else reinterpret_cast<float2 *>(out_w)[slot] = make_float2(g[k].w, w0);
                 } else {
@@ -1093,6 +1101,8 @@ static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geo
     BinArgs ba;
     ba.R = ctx->R; ba.tw = tw; ba.th = th; ba.tiles_x = tiles_x; ba.tiles_y = tiles_y; ba.pmin = pmin; ba.pmax = pmax;
     ba.disc_k2 = ta.disc_k2; ba.exact = exact ? 1 : 0; ba.narrow = exact ? 1 : 0;
+    ba.win_rows = std::max(1, G_WIN_TILES / tiles_x);
+    const int n_win = (tiles_y + ba.win_rows - 1) / ba.win_rows, win_tiles = std::min(tiles_y, ba.win_rows) * tiles_x;
     if (ws.mtile_capacity < n_tiles) {
         void *olds[] = {ws.mband_count, ws.mband_base, ws.mitem_base};
         for (void *q : olds)
@@ -1111,14 +1121,14 @@ static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geo
         while (item_records < GCHUNK_MAX && (double)item_records * 1.41 < want) item_records *= 2;
     }
     TSP_HIP(hipMemsetAsync(ws.mband_count, 0, 2 * (size_t)ws.mtile_capacity * sizeof(int), st));
-    const bool lds = n_tiles <= G_LDS_TILES;
+    const bool lds = win_tiles <= G_LDS_TILES;
     if (!(ctx->kernel_attr_done & (1u << (8 + NW)))) {      // (more than 64 KB of dynamic LDS needs the attribute)
         TSP_HIP(hipFuncSetAttribute((const void *)tile_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_TILES * (int)sizeof(int)));
         TSP_HIP(hipFuncSetAttribute((const void *)tile_fill_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G_LDS_TILES * (int)sizeof(int)));
         ctx->kernel_attr_done |= 1u << (8 + NW);
     }
     const unsigned grid = (unsigned)((n_mid + 256 * TSP_BIN_PER - 1) / (256 * TSP_BIN_PER));
-    hipLaunchKernelGGL(tile_count_kernel, dim3(grid), dim3(256), lds ? n_tiles * sizeof(int) : 0, st, mid_geom, n_mid, ba, ws.mband_count);
+    hipLaunchKernelGGL(tile_count_kernel, dim3(grid, n_win), dim3(256), lds ? win_tiles * sizeof(int) : 0, st, mid_geom, n_mid, ba, ws.mband_count);
     // the sizes of the bins are known on the device only: the prefix pass runs once without the item table to size it, the
     // host reads the two totals (one small copy; the pipeline already synchronises once per frame for the record counts) and grows
     // the bins when needed, then the pass runs again and writes the table
@@ -1139,7 +1149,7 @@ static int bin_mid_records(tsp_context *ctx, TileArgs &ta, const float4 *mid_geo
         TSP_HIP(hipMalloc((void **)&ws.mitem_tile, (size_t)ws.mitem_capacity * sizeof(int)));
     }
     hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(1024), 0, st, (const int *)ws.mband_count, n_tiles, ws.mband_base, ws.mitem_base, ws.mitem_tile, total_items, item_records);
-    hipLaunchKernelGGL((tile_fill_kernel<NW>), dim3(grid), dim3(256), lds ? 2 * n_tiles * sizeof(int) : 0, st, mid_geom, mid_w, n_mid, ba,
+    hipLaunchKernelGGL((tile_fill_kernel<NW>), dim3(grid, n_win), dim3(256), lds ? 2 * win_tiles * sizeof(int) : 0, st, mid_geom, mid_w, n_mid, ba,
                        (float4 *)ws.mband_geom, (float *)ws.mband_w, (const long long *)ws.mband_base, ws.mband_count + ws.mtile_capacity,
                        &ctx->counters->mid_odd_weights);
     TSP_HIP(hipGetLastError());
